@@ -1,0 +1,108 @@
+// Internal declarations shared by the translation units of libtaco_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/taco.h"
+
+// ---- error plumbing -------------------------------------------------------------------------
+void taco_set_error(const char* fmt, ...);
+#define TACO_FAIL(code, ...)   \
+  do {                         \
+    taco_set_error(__VA_ARGS__); \
+    return (code);             \
+  } while (0)
+#define TACO_HIP(call)                                                                      \
+  do {                                                                                      \
+    hipError_t e_ = (call);                                                                 \
+    if (e_ != hipSuccess) TACO_FAIL(TACO_EHIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+  } while (0)
+
+// ---- compile-time capacities of the persistent decoder ----------------------------------------
+// LSTM rows live in registers in chunks of 256 columns (one ds_read_b128 per lane per chunk).
+constexpr int TACO_CHUNK = 256;
+constexpr int TACO_NP = 1;    // prenet-width chunks            -> P   <= 256
+constexpr int TACO_NM = 3;    // memory-width chunks            -> M   <= 768
+constexpr int TACO_NA = 4;    // attention-LSTM hidden chunks   -> R_a <= 1024
+constexpr int TACO_ND = 4;    // decoder-LSTM hidden chunks     -> R_d <= 1024
+constexpr int TACO_MAX_A = 128;
+constexpr int TACO_MAX_F = 32;
+constexpr int TACO_MAX_K = 31;
+constexpr int TACO_MAX_MEL = 127;           // n_mel + 1 gate row <= 128
+constexpr int TACO_MAX_TIN = 1024;          // symbols per utterance
+constexpr int TACO_DEC_THREADS = 512;       // 8 waves: two LSTM gate rows per wave
+constexpr int TACO_UNITS_PER_WG = 4;        // 4 hidden units x 4 gates = 16 rows per LSTM per workgroup
+constexpr int TACO_E_SLOTS = 4;             // energy positions per workgroup = ceil(T_in / n_wg)
+constexpr int TACO_C_SLOTS = 3;             // context columns per workgroup  = ceil(M / n_wg)
+
+// Tagged 8-byte hand-off word: high half = epoch (frame + 1), low half = fp32 payload.
+typedef unsigned long long taco_granule;
+
+// Granule vectors of the decoder, in units of granules from the base; two parities each.
+struct taco_dec_layout {
+  int32_t p1, p, ah, q, e, ctx, dh, mel, beat;   // offsets
+  int32_t per_parity;                            // granules per parity block
+};
+
+struct taco_dec_ctl {      // device-visible control block (zeroed before every launch)
+  uint32_t abort_code;     // first failure code raised by any workgroup (0 = none)
+  uint32_t abort_info;     // vector id / frame of the failed wait
+  uint32_t n_frames;       // frames produced
+  uint32_t reached_max;
+  uint32_t pad_[12];
+};
+
+struct taco_handle_s {
+  int device;
+  int n_cu;
+  taco_dims d;
+  taco_weights w;            // device pointers into `pool` (original checkpoint layout)
+  float* pool;               // owned copy of every weight tensor
+  size_t pool_floats;
+  // folded BatchNorm: y = conv * alpha + beta
+  float* enc_alpha[TACO_MAX_CONVS];
+  float* enc_beta[TACO_MAX_CONVS];
+  float* post_alpha[TACO_MAX_CONVS];
+  float* post_beta[TACO_MAX_CONVS];
+  float* lstm_bias_sum;      // [2][4*H_e]  b_ih + b_hh of the encoder LSTM
+  float* lstm_w_ih_cat;      // [2*4*H_e][E] both directions stacked
+  // workspaces (grow-only)
+  float* ws_act[2];          // activation ping-pong [B][C_max][T]
+  size_t ws_act_floats;
+  float* ws_gx;              // [B][2][4*H_e][T] LSTM input projections
+  size_t ws_gx_floats;
+  taco_granule* enc_gran;    // encoder LSTM hand-off words
+  size_t enc_gran_count;
+  taco_granule* dec_gran;    // decoder hand-off words, 2 parities
+  taco_dec_layout dec_lay;
+  taco_dec_ctl* dec_ctl;     // device
+  taco_dec_ctl* dec_ctl_host;  // pinned host mirror
+  uint32_t* enc_ctl;         // device: [0] abort code of the encoder LSTM kernel
+  hipEvent_t ev_start, ev_stop;
+  int last_frames;
+  int timing_valid;
+};
+
+// ---- launchers implemented in the kernel translation units ----------------------------------
+int taco_launch_embed(taco_handle h, const int64_t* const* ids_dev, const int32_t* lens, int B, int T,
+                      float* x, hipStream_t s);
+// Conv1d(k, pad (k-1)/2) + per-channel affine (folded BatchNorm) + activation (+ residual).
+// in [B][c_in][T], out [B][c_out][T]; columns >= lens[b] are written as zero.
+int taco_launch_conv(const float* in, float* out, const float* w, const float* bias, const float* alpha,
+                     const float* beta, const float* residual, const int32_t* lens, int B, int c_in,
+                     int c_out, int k, int T, int act, hipStream_t s);
+int taco_launch_enc_lstm(taco_handle h, const float* gx, const int32_t* lens, int B, int T, float* memory,
+                         hipStream_t s);
+int taco_launch_memory_tail(taco_handle h, const int64_t* speakers, const int32_t* lens, int B, int T,
+                            float* memory, float* pm, hipStream_t s);
+int taco_launch_decoder(taco_handle h, const float* memory, const float* pm, int T_in, const int32_t* lens,
+                        int b, const uint8_t* masks, int T_cap, int max_steps, float thr, const float* forced_mel,
+                        float* mel, float* gate, float* align, int32_t* n_frames, uint8_t* reached,
+                        hipStream_t s);
+size_t taco_decoder_lds_bytes();
+size_t taco_decoder_granules(int n_wg);
+void taco_decoder_fill_layout(taco_dec_layout* lay, int n_wg);
+int taco_decoder_check_dims(const taco_dims& d, int n_wg);
+int taco_decoder_prepare(taco_handle h);
+int taco_selftest_device(hipStream_t s);

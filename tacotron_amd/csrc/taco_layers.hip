@@ -1,0 +1,349 @@
+// Once-per-utterance stages for gfx950: input vectors, Conv1d + BatchNorm + activation tiles
+// (encoder and postnet), the encoder BiLSTM recurrence, speaker concat + attention memory projection.
+#include "taco_device.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// Input vectors: concatenated per-channel embedding rows / one-hot blocks, channel-major [B][E][T].
+// reference: get_vector + cat + transpose, src/tacotron/model.py:752-773, 585-609.
+// ------------------------------------------------------------------------------------------------
+struct EmbedArgs {
+  const int64_t* ids[TACO_MAX_CHANNELS];
+  const float* table[TACO_MAX_CHANNELS];
+  int width[TACO_MAX_CHANNELS];
+  int rows[TACO_MAX_CHANNELS];
+  int n_channels, E, T, B;
+  const int32_t* lens;
+  float* x;
+};
+
+__global__ __launch_bounds__(256) void taco_embed_kernel(const EmbedArgs a) {
+  const size_t total = (size_t)a.B * a.E * a.T;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int t = (int)(i % a.T);
+    const int e = (int)((i / a.T) % a.E);
+    const int b = (int)(i / ((size_t)a.T * a.E));
+    const int len = a.lens ? a.lens[b] : a.T;
+    float v = 0.0f;
+    if (t < len) {
+      int off = 0;
+#pragma unroll
+      for (int c = 0; c < TACO_MAX_CHANNELS; ++c) {
+        if (c < a.n_channels && e >= off && e < off + a.width[c]) {
+          const int64_t id = a.ids[c][(size_t)b * a.T + t];
+          if (id >= 0 && id < a.rows[c]) {
+            if (a.table[c]) v = a.table[c][(size_t)id * a.width[c] + (e - off)];
+            else v = (id == (int64_t)(e - off)) ? 1.0f : 0.0f;
+          }
+        }
+        if (c < a.n_channels) off += a.width[c];
+      }
+    }
+    a.x[i] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Conv1d(kernel KS, zero padding (KS-1)/2) fused with a per-channel affine (eval BatchNorm folded to
+// y*alpha+beta), an activation and an optional residual add.  One 256-thread workgroup computes a
+// 32-channel x 64-column output tile; input columns and weights are staged through LDS in slabs
+// of 8 input channels; each thread keeps a 2 x 4 register tile.
+// reference: ConvNorm (src/tacotron/layers.py:17-35) + BatchNorm1d in Encoder.inference
+// (src/tacotron/model.py:280-289) and Postnet.forward (205-211); residual add model.py:788-789.
+// ------------------------------------------------------------------------------------------------
+constexpr int CV_CO = 32, CV_TT = 64, CV_CI = 8;
+
+template <int KS>
+__global__ __launch_bounds__(256) void taco_conv_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                        const float* __restrict__ w, const float* __restrict__ bias,
+                                                        const float* __restrict__ alpha, const float* __restrict__ beta,
+                                                        const float* __restrict__ residual, const int32_t* lens,
+                                                        int c_in, int c_out, int T, int act) {
+  constexpr int XW = CV_TT + KS - 1;
+  constexpr int PAD = (KS - 1) / 2;
+  __shared__ float xs[CV_CI][XW + 1];
+  __shared__ float ws[CV_CO][CV_CI * KS + 1];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.z;
+  const int t0 = blockIdx.x * CV_TT;
+  const int co0 = blockIdx.y * CV_CO;
+  const int len = lens ? lens[b] : T;
+  const int co_sub = tid >> 4;       // 0..15 -> channels co_sub*2, +1
+  const int t_sub = tid & 15;        // 0..15 -> columns t_sub*4 .. +3
+  const float* in_b = in + (size_t)b * c_in * T;
+  float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+
+  if (t0 < len) {
+    for (int ci0 = 0; ci0 < c_in; ci0 += CV_CI) {
+      for (int idx = tid; idx < CV_CI * XW; idx += 256) {
+        const int r = idx / XW, c = idx % XW;
+        const int tt = t0 + c - PAD, ci = ci0 + r;
+        xs[r][c] = (ci < c_in && tt >= 0 && tt < len) ? in_b[(size_t)ci * T + tt] : 0.0f;
+      }
+      for (int idx = tid; idx < CV_CO * CV_CI * KS; idx += 256) {
+        const int co = idx / (CV_CI * KS), rem = idx % (CV_CI * KS);
+        const int ci = rem / KS, kk = rem % KS;
+        ws[co][rem] = (co0 + co < c_out && ci0 + ci < c_in)
+                          ? w[((size_t)(co0 + co) * c_in + ci0 + ci) * KS + kk] : 0.0f;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int ci = 0; ci < CV_CI; ++ci) {
+        float xv[4 + KS - 1];
+#pragma unroll
+        for (int i = 0; i < 4 + KS - 1; ++i) xv[i] = xs[ci][t_sub * 4 + i];
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+          const float w0 = ws[co_sub * 2 + 0][ci * KS + kk];
+          const float w1 = ws[co_sub * 2 + 1][ci * KS + kk];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            acc[0][i] = fmaf(w0, xv[i + kk], acc[0][i]);
+            acc[1][i] = fmaf(w1, xv[i + kk], acc[1][i]);
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int co = co0 + co_sub * 2 + r;
+    if (co >= c_out) continue;
+    const float al = alpha ? alpha[co] : 1.0f;
+    const float be = beta ? beta[co] : 0.0f;
+    const float bi = bias ? bias[co] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int t = t0 + t_sub * 4 + i;
+      if (t >= T) continue;
+      float v = 0.0f;
+      if (t < len) {
+        v = (acc[r][i] + bi) * al + be;
+        if (act == 1) v = v > 0.0f ? v : 0.0f;
+        else if (act == 2) v = tanhf(v);
+        if (residual) v += residual[((size_t)b * c_out + co) * T + t];
+      }
+      out[((size_t)b * c_out + co) * T + t] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Encoder BiLSTM recurrence, one utterance per launch.  The input projections W_ih x_t + b_ih + b_hh
+// of all steps are computed beforehand (a kernel-size-1 conv); this kernel runs the sequential part:
+// 2 * ceil(H/4) resident workgroups (one half per direction), recurrent rows in registers, hidden
+// state exchanged per step through tagged granules (double-buffered by step parity).
+// reference: nn.LSTM(bidirectional) in Encoder.inference, src/tacotron/model.py:253-260, 280-289;
+// for padded batches the reverse direction starts at each utterance's own last symbol
+// (pack_padded_sequence semantics, model.py:262-278).
+// ------------------------------------------------------------------------------------------------
+constexpr int EL_CH = 2;   // recurrent row chunks of 256 -> H_e <= 512
+
+struct EncLstmArgs {
+  const float* w_hh[2];   // [4H][H]
+  const float* gx;        // [2][4H][T] this utterance
+  float* memory;          // [T][M] this utterance
+  const int32_t* lens;    // device, or NULL = T symbols
+  int b;                  // utterance index into lens
+  int H, T, M, n_wg_dir;
+  taco_granule* gran;     // [2 dirs][2 parities][512]
+  uint32_t* ctl;
+  unsigned long long timeout_ticks;
+};
+
+__global__ __launch_bounds__(1024) void taco_enc_lstm_kernel(const EncLstmArgs a) {
+  __shared__ __attribute__((aligned(16))) float xh[EL_CH * TACO_CHUNK];
+  __shared__ float gates[16];
+  __shared__ float cells[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int len = a.lens ? a.lens[a.b] : a.T;
+  const int dir = blockIdx.x / a.n_wg_dir;
+  const int jj = blockIdx.x % a.n_wg_dir;
+  const int unit = wave >> 2, gate_id = wave & 3;
+  const int gu = jj * 4 + unit;
+  const bool active = gu < a.H;
+  const int row = gate_id * a.H + gu;
+  float wr[EL_CH][4];
+#pragma unroll
+  for (int c = 0; c < EL_CH; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int col = c * TACO_CHUNK + lane * 4 + e;
+      wr[c][e] = (active && col < a.H) ? a.w_hh[dir][(size_t)row * a.H + col] : 0.0f;
+    }
+  for (int i = tid; i < EL_CH * TACO_CHUNK; i += 1024) xh[i] = 0.0f;
+  if (tid < 4) cells[tid] = 0.0f;
+  __syncthreads();
+
+  taco_wait_ctx wctx;
+  wctx.abort_word = (taco_gu32*)a.ctl;
+  wctx.deadline = wall_clock64() + a.timeout_ticks;
+  wctx.failed = 0;
+  taco_granule* gdir = a.gran + (size_t)dir * 2 * 512;
+  const float* gx = a.gx + (size_t)dir * 4 * a.H * a.T;
+
+  for (int s = 0; s < len; ++s) {
+    const int t = dir == 0 ? s : len - 1 - s;
+    float gx_v = 0.0f;
+    if (active && lane == 0) gx_v = gx[(size_t)row * a.T + t];
+    if (s > 0) {
+      taco_gather<1024>(gdir + (size_t)((s - 1) & 1) * 512, a.H, (unsigned)s, xh, wctx, 0xE00u);
+      if (__syncthreads_or(wctx.failed)) break;
+      wctx.deadline = wall_clock64() + a.timeout_ticks;
+    }
+    if (active) {
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < EL_CH; ++c) {
+        const float4 x = *reinterpret_cast<const float4*>(xh + c * TACO_CHUNK + lane * 4);
+        acc[0] = fmaf(wr[c][0], x.x, acc[0]);
+        acc[1] = fmaf(wr[c][1], x.y, acc[1]);
+        acc[2] = fmaf(wr[c][2], x.z, acc[2]);
+        acc[3] = fmaf(wr[c][3], x.w, acc[3]);
+      }
+      const float sum = taco_wave_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));
+      if (lane == 0) gates[wave] = gx_v + sum;
+    }
+    __syncthreads();
+    if (tid < 4 && jj * 4 + tid < a.H) {
+      const float ig = taco_sigmoid(gates[tid * 4 + 0]);
+      const float fg = taco_sigmoid(gates[tid * 4 + 1]);
+      const float gg = tanhf(gates[tid * 4 + 2]);
+      const float og = taco_sigmoid(gates[tid * 4 + 3]);
+      const float c = fg * cells[tid] + ig * gg;
+      cells[tid] = c;
+      const float hv = og * tanhf(c);
+      taco_publish(gdir + (size_t)(s & 1) * 512, jj * 4 + tid, (unsigned)s + 1u, hv);
+      a.memory[(size_t)t * a.M + dir * a.H + jj * 4 + tid] = hv;
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Speaker vector concat and processed_memory = memory_layer(memory): one workgroup per (b, t).
+// reference: src/tacotron/model.py:779-782 (speaker concat), 403 (memory_layer, no bias).
+// ------------------------------------------------------------------------------------------------
+struct TailArgs {
+  const int64_t* speakers;
+  const float* spk_table;
+  const float* memory_w;   // [A][M]
+  const int32_t* lens;
+  float* memory;           // [B][T][M]
+  float* pm;               // [B][T][A]
+  int T, M, A, S, H2, spk_rows;
+};
+
+__global__ __launch_bounds__(256) void taco_memory_tail_kernel(const TailArgs a) {
+  __shared__ float row[TACO_NM * TACO_CHUNK];
+  const int t = blockIdx.x, b = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int len = a.lens ? a.lens[b] : a.T;
+  float* mem = a.memory + ((size_t)b * a.T + t) * a.M;
+  float* pm = a.pm + ((size_t)b * a.T + t) * a.A;
+  if (t >= len) {
+    for (int k = tid; k < a.M; k += 256) mem[k] = 0.0f;
+    for (int k = tid; k < a.A; k += 256) pm[k] = 0.0f;
+    return;
+  }
+  for (int k = tid; k < a.H2; k += 256) row[k] = mem[k];
+  if (a.S > 0) {
+    const int64_t id = a.speakers[(size_t)b * a.T + t];
+    for (int k = tid; k < a.S; k += 256) {
+      float v = 0.0f;
+      if (id >= 0 && id < a.spk_rows) v = a.spk_table ? a.spk_table[(size_t)id * a.S + k] : (id == k ? 1.0f : 0.0f);
+      mem[a.H2 + k] = v;
+      row[a.H2 + k] = v;
+    }
+  }
+  __syncthreads();
+  for (int aa = wave; aa < a.A; aa += 4) {
+    float acc = 0.0f;
+    for (int k = lane; k < a.M; k += 64) acc = fmaf(a.memory_w[(size_t)aa * a.M + k], row[k], acc);
+    acc = taco_wave_sum(acc);
+    if (lane == 0) pm[aa] = acc;
+  }
+}
+
+}  // namespace
+
+int taco_launch_embed(taco_handle h, const int64_t* const* ids_dev, const int32_t* lens, int B, int T,
+                      float* x, hipStream_t s) {
+  EmbedArgs a;
+  const taco_dims& d = h->d;
+  for (int c = 0; c < TACO_MAX_CHANNELS; ++c) {
+    a.ids[c] = c < d.n_channels ? ids_dev[c] : nullptr;
+    a.table[c] = c < d.n_channels ? h->w.ch_table[c] : nullptr;
+    a.width[c] = c < d.n_channels ? d.ch_width[c] : 0;
+    a.rows[c] = c < d.n_channels ? d.ch_rows[c] : 0;
+    if (c < d.n_channels && !a.ids[c]) TACO_FAIL(TACO_EINVAL, "ids[%d] is NULL", c);
+  }
+  a.n_channels = d.n_channels; a.E = d.E; a.T = T; a.B = B; a.lens = lens; a.x = x;
+  const size_t total = (size_t)B * d.E * T;
+  const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  hipLaunchKernelGGL(taco_embed_kernel, dim3(blocks), dim3(256), 0, s, a);
+  TACO_HIP(hipGetLastError());
+  return TACO_OK;
+}
+
+int taco_launch_conv(const float* in, float* out, const float* w, const float* bias, const float* alpha,
+                     const float* beta, const float* residual, const int32_t* lens, int B, int c_in,
+                     int c_out, int k, int T, int act, hipStream_t s) {
+  const dim3 grid((T + CV_TT - 1) / CV_TT, (c_out + CV_CO - 1) / CV_CO, B);
+  switch (k) {
+#define TACO_CONV_CASE(KS)                                                                          \
+  case KS:                                                                                          \
+    hipLaunchKernelGGL(taco_conv_kernel<KS>, grid, dim3(256), 0, s, in, out, w, bias, alpha, beta,  \
+                       residual, lens, c_in, c_out, T, act);                                        \
+    break;
+    TACO_CONV_CASE(1)
+    TACO_CONV_CASE(3)
+    TACO_CONV_CASE(5)
+    TACO_CONV_CASE(7)
+    TACO_CONV_CASE(9)
+#undef TACO_CONV_CASE
+    default:
+      TACO_FAIL(TACO_EINVAL, "convolution kernel size %d is not one of 1,3,5,7,9", k);
+  }
+  TACO_HIP(hipGetLastError());
+  return TACO_OK;
+}
+
+int taco_launch_enc_lstm(taco_handle h, const float* gx, const int32_t* lens, int B, int T, float* memory,
+                         hipStream_t s) {
+  const taco_dims& d = h->d;
+  const int n_wg_dir = (d.H_e + 3) / 4;
+  if (d.H_e > EL_CH * TACO_CHUNK || 2 * n_wg_dir > h->n_cu)
+    TACO_FAIL(TACO_EINVAL, "encoder LSTM width %d exceeds the recurrence kernel's capacity", d.H_e);
+  for (int b = 0; b < B; ++b) {
+    EncLstmArgs a;
+    a.w_hh[0] = h->w.enc_lstm_w_hh[0];
+    a.w_hh[1] = h->w.enc_lstm_w_hh[1];
+    a.gx = gx + (size_t)b * 8 * d.H_e * T;
+    a.memory = memory + (size_t)b * T * d.M;
+    a.lens = lens; a.b = b;
+    a.H = d.H_e; a.T = T; a.M = d.M; a.n_wg_dir = n_wg_dir;
+    a.gran = h->enc_gran; a.ctl = h->enc_ctl;
+    a.timeout_ticks = 20000000ull;
+    TACO_HIP(hipMemsetAsync(h->enc_gran, 0, h->enc_gran_count * sizeof(taco_granule), s));
+    hipLaunchKernelGGL(taco_enc_lstm_kernel, dim3(2 * n_wg_dir), dim3(1024), 0, s, a);
+    TACO_HIP(hipGetLastError());
+  }
+  return TACO_OK;
+}
+
+int taco_launch_memory_tail(taco_handle h, const int64_t* speakers, const int32_t* lens, int B, int T,
+                            float* memory, float* pm, hipStream_t s) {
+  const taco_dims& d = h->d;
+  if (d.M > TACO_NM * TACO_CHUNK) TACO_FAIL(TACO_EINVAL, "memory width %d too large", d.M);
+  if (d.S > 0 && !speakers) TACO_FAIL(TACO_EINVAL, "speakers is NULL but the checkpoint models speakers");
+  TailArgs a;
+  a.speakers = speakers; a.spk_table = h->w.spk_table; a.memory_w = h->w.memory_w; a.lens = lens;
+  a.memory = memory; a.pm = pm; a.T = T; a.M = d.M; a.A = d.A; a.S = d.S; a.H2 = 2 * d.H_e;
+  a.spk_rows = d.spk_rows;
+  hipLaunchKernelGGL(taco_memory_tail_kernel, dim3(T, B), dim3(256), 0, s, a);
+  TACO_HIP(hipGetLastError());
+  return TACO_OK;
+}

@@ -1,0 +1,229 @@
+"""``Tacotron2`` with the reference's call surface, computed by the HIP library.
+
+Keeps the constructor, ``load_state_dict`` / ``to`` / ``eval`` and the
+``inference(symbols, stresses, tones, durations, speakers, max_decoder_steps)`` method of the
+reference's module (reference: src/tacotron/model.py:612-688, 751-791) so that code written
+against it - in particular ``Synthesizer`` - runs unchanged, but it holds no torch arithmetic:
+every stage is a call into ``libtaco_hip.so`` on the device's current stream.  torch is used for
+device memory, streams and the CPU random generator that defines the prenet dropout masks.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import hashlib
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from tacotron_amd import _lib, abi
+from tacotron_amd.config import HParams
+
+_UNLIMITED_START = 8192     # first capacity tried when max_decoder_steps == 0 (no limit)
+
+
+class Tacotron2:
+  def __init__(self, hparams: HParams, n_symbols: int, n_stresses: Optional[int], n_speakers: Optional[int],
+               n_tones: Optional[int], n_durations: Optional[int]):
+    self.hparams = hparams
+    self.counts = dict(n_symbols=n_symbols, n_stresses=n_stresses, n_speakers=n_speakers, n_tones=n_tones,
+                       n_durations=n_durations)
+    self.cdims, self.dims = abi.build_dims(hparams, **self.counts)
+    self.gate_threshold = float(hparams.gate_threshold)
+    self.n_mel_channels = hparams.n_mel_channels
+    self._state: Optional[Dict[str, torch.Tensor]] = None
+    self._handle: Optional[C.c_void_p] = None
+    self._keep: List[torch.Tensor] = []
+    self.device: Optional[torch.device] = None
+    self._mask_cache: Dict[bytes, torch.Tensor] = {}
+    self.training = False
+
+  # ---- module-like plumbing -------------------------------------------------------------------
+  def load_state_dict(self, state: Dict[str, torch.Tensor]) -> None:
+    self._state = state
+    if self._handle is not None:
+      self._rebuild()
+
+  def eval(self) -> "Tacotron2":
+    return self
+
+  def to(self, device, non_blocking: bool = False) -> "Tacotron2":
+    device = torch.device(device)
+    if device.type != "cuda":
+      raise RuntimeError(f"this Tacotron2 runs on an AMD GPU only (got device '{device}'); there is no CPU path")
+    if device.index is None:
+      device = torch.device("cuda", torch.cuda.current_device())
+    self.device = device
+    self._rebuild()
+    return self
+
+  def _rebuild(self) -> None:
+    if self._state is None:
+      raise RuntimeError("load_state_dict must be called before moving the model to a device")
+    self.close()
+    weights, keep = abi.bind_weights(self.hparams, self.dims, self._state, self.device)
+    handle = C.c_void_p()
+    torch.cuda.synchronize(self.device)
+    _lib.check(_lib.lib().taco_create(C.byref(self.cdims), C.byref(weights), self.device.index, C.byref(handle)))
+    self._handle = handle
+    del keep          # the library owns a copy now
+
+  def close(self) -> None:
+    if self._handle is not None:
+      _lib.lib().taco_destroy(self._handle)
+      self._handle = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:
+      pass
+
+  @property
+  def step_weight_bytes(self) -> int:
+    return int(_lib.lib().taco_step_weight_bytes(self._require()))
+
+  def _require(self) -> C.c_void_p:
+    if self._handle is None:
+      raise RuntimeError("model is not on a device yet: call .to('cuda:N') first")
+    return self._handle
+
+  def _stream(self) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+  # ---- prenet dropout masks -------------------------------------------------------------------
+  def masks_from_global_rng(self, n_steps: int) -> torch.Tensor:
+    """uint8 [n_steps, 2, P] on the device, drawn from torch's global CPU generator exactly as the
+    reference's prenet would draw them during this call (see tacotron_amd.masks).  The draw for a
+    given generator state is cached, so a caller that re-seeds with the same seed before every
+    line (as the CLI does) uploads the masks once."""
+    state = torch.get_rng_state()
+    key = hashlib.sha1(state.numpy().tobytes()).digest() + n_steps.to_bytes(4, "little")
+    hit = self._mask_cache.get(key)
+    if hit is not None:
+      return hit
+    from tacotron_amd import masks as masks_mod
+    P = self.dims.P
+    masks_mod.prenet_keep_masks(0, 1, P)   # settles whether one bulk draw reproduces the per-call stream
+    if masks_mod._bulk_equals_stepwise[P]:
+      flat = torch.empty(n_steps * 2 * P, dtype=torch.float32).bernoulli_(0.5)
+      host = flat.to(torch.uint8).view(n_steps, 2, P)
+    else:
+      host = torch.empty(n_steps, 2, P, dtype=torch.uint8)
+      row = torch.empty(1, P, dtype=torch.float32)
+      for t in range(n_steps):
+        for layer in range(2):
+          row.bernoulli_(0.5)
+          host[t, layer] = row[0].to(torch.uint8)
+    dev = host.to(self.device)
+    if len(self._mask_cache) > 8:
+      self._mask_cache.clear()
+    self._mask_cache[key] = dev
+    return dev
+
+  # ---- stages ------------------------------------------------------------------------------------
+  def encode(self, ids: Sequence[torch.Tensor], speakers: Optional[torch.Tensor],
+             lens: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
+    h = self._require()
+    ids = [i.to(device=self.device, dtype=torch.int64).contiguous() for i in ids]
+    if len(ids) != self.cdims.n_channels:
+      raise ValueError(f"expected {self.cdims.n_channels} id tensors, got {len(ids)}")
+    B, T = ids[0].shape
+    for c, t in enumerate(ids):
+      if tuple(t.shape) != (B, T):
+        raise ValueError("id tensors differ in shape")
+      if T > 0 and (int(t.min()) < 0 or int(t.max()) >= self.cdims.ch_rows[c]):
+        raise IndexError(f"id out of range in input channel {c}")
+    spk = None
+    if self.dims.S > 0:
+      if speakers is None:
+        raise ValueError("the checkpoint models speakers: a speakers tensor is required")
+      spk = speakers.to(device=self.device, dtype=torch.int64).contiguous()
+      if int(spk.min()) < 0 or int(spk.max()) >= self.cdims.spk_rows:
+        raise IndexError("speaker id out of range")
+    ln = None if lens is None else lens.to(device=self.device, dtype=torch.int32).contiguous()
+    memory = torch.empty(B, T, self.dims.M, device=self.device, dtype=torch.float32)
+    pm = torch.empty(B, T, self.dims.A, device=self.device, dtype=torch.float32)
+    arr = (C.c_void_p * len(ids))(*[C.c_void_p(t.data_ptr()) for t in ids])
+    _lib.check(_lib.lib().taco_encode(
+      h, arr, None if spk is None else C.c_void_p(spk.data_ptr()),
+      None if ln is None else C.c_void_p(ln.data_ptr()), B, T, C.c_void_p(memory.data_ptr()),
+      C.c_void_p(pm.data_ptr()), self._stream()))
+    return memory, pm
+
+  def decode(self, memory: torch.Tensor, pm: torch.Tensor, lens: Optional[torch.Tensor], masks: torch.Tensor,
+             max_steps: int, forced_mel: Optional[torch.Tensor] = None, T_cap: Optional[int] = None,
+             want_align: bool = True, gate_threshold: Optional[float] = None):
+    h = self._require()
+    B, T, _ = memory.shape
+    T_cap = int(T_cap or max_steps)
+    masks = masks.to(device=self.device, dtype=torch.uint8).contiguous()
+    if masks.shape[0] < max_steps or tuple(masks.shape[1:]) != (2, self.dims.P):
+      raise ValueError(f"masks must be [>= {max_steps}, 2, {self.dims.P}], got {tuple(masks.shape)}")
+    ln = None if lens is None else lens.to(device=self.device, dtype=torch.int32).contiguous()
+    mel = torch.empty(B, self.dims.n_mel, T_cap, device=self.device, dtype=torch.float32)
+    gate = torch.empty(B, T_cap, device=self.device, dtype=torch.float32)
+    align = torch.empty(B, T_cap, T, device=self.device, dtype=torch.float32) if want_align else None
+    n_frames = torch.zeros(B, device=self.device, dtype=torch.int32)
+    reached = torch.zeros(B, device=self.device, dtype=torch.uint8)
+    if forced_mel is not None:
+      forced_mel = forced_mel.to(device=self.device, dtype=torch.float32).contiguous()
+      if tuple(forced_mel.shape) != (B, self.dims.n_mel, T_cap):
+        raise ValueError("forced_mel must be [B, n_mel, T_cap]")
+    thr = self.gate_threshold if gate_threshold is None else float(gate_threshold)
+    p = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
+    _lib.check(_lib.lib().taco_decode(
+      h, p(memory.contiguous()), p(pm.contiguous()), p(ln), B, T, p(masks), T_cap, int(max_steps), C.c_float(thr),
+      p(forced_mel), p(mel), p(gate), p(align), p(n_frames), p(reached), self._stream()))
+    return mel, gate, align, n_frames, reached
+
+  def postnet(self, mel: torch.Tensor, n_frames: Optional[torch.Tensor]) -> torch.Tensor:
+    h = self._require()
+    B, _, T_cap = mel.shape
+    out = torch.empty_like(mel)
+    nf = None if n_frames is None else n_frames.to(device=self.device, dtype=torch.int32).contiguous()
+    _lib.check(_lib.lib().taco_postnet(h, C.c_void_p(mel.data_ptr()), None if nf is None else C.c_void_p(nf.data_ptr()),
+                                       B, T_cap, C.c_void_p(out.data_ptr()), self._stream()))
+    return out
+
+  def last_decode_timing(self) -> Tuple[float, int]:
+    us, frames = C.c_double(), C.c_int32()
+    _lib.check(_lib.lib().taco_last_decode_timing(self._require(), C.byref(us), C.byref(frames)))
+    return us.value, frames.value
+
+  # ---- whole path ------------------------------------------------------------------------------
+  def inference_batch(self, symbols: torch.Tensor, stresses: Optional[torch.Tensor], tones: Optional[torch.Tensor],
+                      durations: Optional[torch.Tensor], speakers: Optional[torch.Tensor],
+                      lens: Optional[torch.Tensor], max_decoder_steps: int, masks: Optional[torch.Tensor] = None,
+                      want_align: bool = True):
+    """Padded batch [B, T_in] with per-utterance lengths; every utterance is computed exactly as an
+    unpadded B=1 call would be (the reference has no batched inference).  Returns padded tensors
+    ``(mel [B,n_mel,T_cap], mel_postnet, gate [B,T_cap], alignments [B,T_cap,T_in] or None,
+    n_frames [B] int32, reached_max [B] uint8)``."""
+    ids = [t for t in (symbols, stresses, tones, durations) if t is not None]
+    memory, pm = self.encode(ids, speakers, lens)
+    limit = int(max_decoder_steps)
+    cap = limit if limit > 0 else _UNLIMITED_START
+    rng_at_entry = torch.get_rng_state()
+    while True:
+      torch.set_rng_state(rng_at_entry)     # every attempt draws the same mask stream
+      mk = masks if masks is not None else self.masks_from_global_rng(cap)
+      mel, gate, align, n_frames, reached = self.decode(memory, pm, lens, mk, cap, want_align=want_align)
+      if limit > 0 or not bool(reached.any()):
+        break
+      cap *= 2                  # no limit requested: rerun with more room (same seed -> same frames)
+    if limit <= 0:
+      reached = torch.zeros_like(reached)
+    post = self.postnet(mel, n_frames)
+    return mel, post, gate, align, n_frames, reached
+
+  def inference(self, symbols: torch.Tensor, stresses: Optional[torch.Tensor], tones: Optional[torch.Tensor],
+                durations: Optional[torch.Tensor], speakers: Optional[torch.Tensor], max_decoder_steps: int):
+    """Same arguments, result tuple, shapes and dtypes as the reference's ``Tacotron2.inference``
+    for its only supported batch size, 1: ``(mel [1,n_mel,T], mel_postnet [1,n_mel,T],
+    gate [1,T,1], alignments [1,T,T_in], reached_max_decoder_steps: bool)``."""
+    if symbols.dim() != 2 or symbols.shape[0] != 1:
+      raise ValueError("inference() takes one utterance, shaped [1, T_in] (use inference_batch for more)")
+    mel, post, gate, align, n_frames, reached = self.inference_batch(
+      symbols, stresses, tones, durations, speakers, None, max_decoder_steps)
+    n = int(n_frames[0])
+    return (mel[:, :, :n], post[:, :, :n], gate[:, :n].unsqueeze(-1), align[:, :n, :], bool(reached[0]))

@@ -1,0 +1,236 @@
+"""``Synthesizer``: checkpoint -> model on the GPU, symbol lines -> mel spectrograms.
+
+Same constructor, attributes, ``infer`` signature and ``InferenceResult`` record as the
+reference's synthesis driver (reference: src/tacotron/synthesizer.py:24-241), with the model's
+arithmetic done by the HIP library (``tacotron_amd.model.Tacotron2``).  ``infer_batch`` is an
+addition: the reference synthesizes one line per call.
+"""
+from __future__ import annotations
+
+import logging
+import os
+import random
+import time
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Set, Tuple, Union
+
+import numpy as np
+import torch
+
+from tacotron_amd import frontend
+from tacotron_amd.checkpoint import (KEY_DURATION_MAPPING, KEY_MODEL_STATE, KEY_SPEAKER_MAPPING,
+                                     KEY_STRESS_MAPPING, KEY_SYMBOL_MAPPING, KEY_TONE_MAPPING, CheckpointDict,
+                                     get_hparams, validate)
+from tacotron_amd.config import apply_custom_hparams
+from tacotron_amd.model import Tacotron2
+
+
+@dataclass
+class InferenceResult:
+  sampling_rate: int
+  reached_max_decoder_steps: bool
+  inference_duration_s: float
+  mel_outputs_postnet: np.ndarray
+  mel_outputs: Optional[np.ndarray]
+  gate_outputs: Optional[np.ndarray]
+  alignments: Optional[np.ndarray]
+  unmappable_symbols: Optional[Set[str]]
+  unmappable_stresses: Optional[Set[str]]
+  unmappable_tones: Optional[Set[str]]
+  unmappable_durations: Optional[Set[str]]
+  duration_s: float
+
+
+def get_default_device() -> torch.device:
+  """First GPU (reference: src/tacotron/utils.py:29-35, which falls back to the CPU; this
+  implementation has no CPU path and raises instead)."""
+  if torch.cuda.device_count() < 1:
+    raise RuntimeError("no GPU is visible; tacotron_amd needs an MI355X (there is no CPU path)")
+  return torch.device("cuda:0")
+
+
+def init_global_seeds(seed: int) -> None:
+  """Seeds every generator the reference seeds before an inference call
+  (reference: src/tacotron/utils.py:440-451)."""
+  os.environ["PYTHONHASHSEED"] = str(seed)
+  random.seed(seed)
+  np.random.seed(seed)
+  torch.manual_seed(seed)
+  if torch.cuda.is_available():
+    torch.cuda.manual_seed(seed)
+
+
+def spectrogram_duration_s(n_frames: int, n_fft: int, hop_length: int, sr: int = 22050) -> float:
+  """What ``librosa.get_duration(S=mel, n_fft=, hop_length=)`` returns for a centred spectrogram
+  with ``n_frames`` columns; the reference does not pass a sampling rate, so librosa's default
+  22050 applies whatever the checkpoint's rate is (reference: src/tacotron/synthesizer.py:219-220)."""
+  n_samples = n_fft + hop_length * (n_frames - 1)
+  n_samples = n_samples - 2 * int(n_fft // 2)
+  return float(n_samples) / sr
+
+
+@dataclass
+class _Prepared:
+  ids: Dict[str, Optional[List[int]]]
+  speaker_id: Optional[int]
+  unmappable_symbols: Optional[Set[str]]
+  unmappable_stresses: Optional[Set[str]]
+  unmappable_tones: Optional[Set[str]]
+  unmappable_durations: Optional[Set[str]]
+
+
+class Synthesizer:
+  def __init__(self, checkpoint: CheckpointDict, custom_hparams: Optional[Dict[str, str]] = None,
+               device: Optional[Union[str, torch.device]] = None):
+    validate(checkpoint)
+    self.device = torch.device(device) if device is not None else get_default_device()
+    hparams = apply_custom_hparams(get_hparams(checkpoint), custom_hparams)
+    self.hparams = hparams
+
+    def mapping(key: str, used: bool):
+      if not used:
+        return None
+      if key not in checkpoint:
+        raise KeyError(f"checkpoint lacks '{key}' although its hparams use that channel")
+      return checkpoint[key]
+
+    self.symbol_mapping = checkpoint[KEY_SYMBOL_MAPPING]
+    self.stress_mapping = mapping(KEY_STRESS_MAPPING, hparams.use_stress_embedding)
+    self.tone_mapping = mapping(KEY_TONE_MAPPING, hparams.use_tone_embedding)
+    self.duration_mapping = mapping(KEY_DURATION_MAPPING, hparams.use_duration_embedding)
+    self.speaker_mapping = mapping(KEY_SPEAKER_MAPPING, hparams.use_speaker_embedding)
+
+    def count(m):
+      return None if m is None else frontend.get_mappings_count(m)
+
+    model = Tacotron2(hparams, n_symbols=count(self.symbol_mapping), n_stresses=count(self.stress_mapping),
+                      n_speakers=count(self.speaker_mapping), n_tones=count(self.tone_mapping),
+                      n_durations=count(self.duration_mapping))
+    model.load_state_dict(checkpoint[KEY_MODEL_STATE])
+    self.model = model.to(self.device).eval()
+
+  def get_sampling_rate(self) -> int:
+    return self.hparams.sampling_rate
+
+  # ---- host logic: symbols -> ids, dropping positions no mapping knows ---------------------------
+  def _prepare(self, symbols: Sequence[str], speaker: Optional[str]) -> _Prepared:
+    logger = logging.getLogger(__name__)
+    cores, stresses, tones, durations = frontend.get_map_keys(symbols, self.hparams)
+    speaker_id = None
+    if self.hparams.use_speaker_embedding:
+      if speaker not in self.speaker_mapping:
+        raise KeyError(f"Speaker '{speaker}' is not in the checkpoint's speaker mapping")
+      speaker_id = self.speaker_mapping[speaker]
+
+    unmappable: Set[int] = set()
+
+    def channel(keys, mapping, what):
+      if keys is None:
+        return None, None
+      ids = frontend.get_mapped_indices(keys, mapping)
+      bad = {i for i, v in enumerate(ids) if v is None}
+      unknown = None
+      if bad:
+        unknown = {keys[i] for i in bad}
+        logger.warning(f"Unknown {what}: {' '.join(sorted(unknown))}")
+        unmappable.update(bad)
+      return ids, unknown
+
+    stress_ids, bad_stresses = channel(stresses, self.stress_mapping, "stress(es)")
+    tone_ids, bad_tones = channel(tones, self.tone_mapping, "tone(s)")
+    duration_ids, bad_durations = channel(durations, self.duration_mapping, "duration(s)")
+    symbol_ids, bad_symbols = channel(cores, self.symbol_mapping, "symbol(s)")
+
+    def keep(ids):
+      return None if ids is None else [v for i, v in enumerate(ids) if i not in unmappable]
+
+    logger.debug("|".join(s if i not in unmappable else f"[{s}]" for i, s in enumerate(symbols)))
+    return _Prepared(
+      ids=dict(symbols=keep(symbol_ids), stresses=keep(stress_ids), tones=keep(tone_ids),
+               durations=keep(duration_ids)),
+      speaker_id=speaker_id, unmappable_symbols=bad_symbols, unmappable_stresses=bad_stresses,
+      unmappable_tones=bad_tones, unmappable_durations=bad_durations)
+
+  def _result(self, prep: _Prepared, mel_post: np.ndarray, reached: bool, seconds: float, mel=None, gate=None,
+              align=None) -> InferenceResult:
+    return InferenceResult(
+      sampling_rate=self.hparams.sampling_rate, reached_max_decoder_steps=reached,
+      inference_duration_s=seconds, mel_outputs_postnet=mel_post, mel_outputs=mel, gate_outputs=gate,
+      alignments=align, unmappable_symbols=prep.unmappable_symbols, unmappable_stresses=prep.unmappable_stresses,
+      unmappable_tones=prep.unmappable_tones, unmappable_durations=prep.unmappable_durations,
+      duration_s=spectrogram_duration_s(mel_post.shape[-1], self.hparams.filter_length, self.hparams.hop_length))
+
+  def infer(self, symbols: Sequence[str], speaker: Optional[str], max_decoder_steps: int = 3000, seed: int = 0,
+            include_stats: bool = False) -> InferenceResult:
+    prep = self._prepare(symbols, speaker)
+    init_global_seeds(seed)
+
+    def tensor(ids):
+      return None if ids is None else torch.tensor([ids], dtype=torch.int64, device=self.device)
+
+    symbol_tensor = tensor(prep.ids["symbols"])
+    speaker_tensor = None
+    if self.hparams.use_speaker_embedding:
+      speaker_tensor = torch.full(tuple(symbol_tensor.shape), prep.speaker_id, dtype=torch.int64, device=self.device)
+
+    torch.cuda.synchronize(self.device)
+    start = time.perf_counter()
+    mel, mel_post, gate, align, reached = self.model.inference(
+      symbols=symbol_tensor, stresses=tensor(prep.ids["stresses"]), tones=tensor(prep.ids["tones"]),
+      durations=tensor(prep.ids["durations"]), speakers=speaker_tensor, max_decoder_steps=max_decoder_steps)
+    torch.cuda.synchronize(self.device)
+    seconds = time.perf_counter() - start
+
+    def to_np(t):
+      return t.squeeze(0).cpu().numpy()
+
+    res = self._result(prep, to_np(mel_post), reached, seconds)
+    if include_stats:
+      res.mel_outputs, res.gate_outputs, res.alignments = to_np(mel), to_np(gate), to_np(align)
+    return res
+
+  def infer_batch(self, lines: Sequence[Sequence[str]], speaker: Optional[str], max_decoder_steps: int = 3000,
+                  seed: int = 0, include_stats: bool = False) -> List[InferenceResult]:
+    """Synthesizes several lines in one padded batch; every line gets the result ``infer`` would
+    give it (same seed for each, as the CLI reuses one seed for all lines:
+    src/tacotron_cli/inference.py:137-141).  ``inference_duration_s`` is the batch time / lines."""
+    if len(lines) == 0:
+      return []
+    preps = [self._prepare(line, speaker) for line in lines]
+    lens = [len(p.ids["symbols"]) for p in preps]
+    if min(lens) < 1:
+      raise ValueError("a line has no mappable symbol")
+    T = max(lens)
+    init_global_seeds(seed)
+
+    def padded(name):
+      if preps[0].ids[name] is None:
+        return None
+      out = torch.zeros(len(preps), T, dtype=torch.int64)
+      for b, p in enumerate(preps):
+        out[b, :lens[b]] = torch.tensor(p.ids[name], dtype=torch.int64)
+      return out.to(self.device)
+
+    speakers = None
+    if self.hparams.use_speaker_embedding:
+      speakers = torch.full((len(preps), T), preps[0].speaker_id, dtype=torch.int64, device=self.device)
+    lens_t = torch.tensor(lens, dtype=torch.int32, device=self.device)
+    torch.cuda.synchronize(self.device)
+    start = time.perf_counter()
+    mel, post, gate, align, n_frames, reached = self.model.inference_batch(
+      padded("symbols"), padded("stresses"), padded("tones"), padded("durations"), speakers, lens_t,
+      max_decoder_steps, want_align=include_stats)
+    torch.cuda.synchronize(self.device)
+    seconds = (time.perf_counter() - start) / len(preps)
+    n_frames = n_frames.cpu().tolist()
+    reached = reached.cpu().tolist()
+    out = []
+    for b, p in enumerate(preps):
+      n = n_frames[b]
+      res = self._result(p, post[b, :, :n].cpu().numpy(), bool(reached[b]), seconds)
+      if include_stats:
+        res.mel_outputs = mel[b, :, :n].cpu().numpy()
+        res.gate_outputs = gate[b, :n].unsqueeze(-1).cpu().numpy()
+        res.alignments = align[b, :n, :lens[b]].cpu().numpy()
+      out.append(res)
+    return out

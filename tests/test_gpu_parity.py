@@ -1,0 +1,251 @@
+"""Parity of the HIP path (through the C ABI in libtaco_hip.so) with the CPU oracle and with the
+reference's own outputs (tests/golden).  Needs a real MI355X: every test is marked ``gpu``.
+
+Tolerances (fp32 everywhere, absolute, on the log-mel scale; summation orders differ):
+  * teacher-forced frames vs the reference:   mel 1e-4, gate 1e-4, alignments 1e-4
+  * encoder outputs vs the oracle:            1e-4
+  * postnet vs the oracle on the same input:  2e-4
+  * free-running: the stop frame index must be IDENTICAL to the reference's; frames 1e-3
+    (the synthetic random-weight models amplify rounding differences slowly over frames)
+"""
+import numpy as np
+import pytest
+import torch
+
+from tacotron_amd import abi, checkpoint as ckpt_mod, scenarios
+from tacotron_amd.masks import prenet_keep_masks
+from conftest import golden_ids, load_golden, oracle_model, scenario_checkpoint
+
+pytestmark = pytest.mark.gpu
+
+TF_TOL = 1e-4
+FREE_TOL = 1e-3
+_models = {}
+
+
+def gpu_model(name, gate):
+  from tacotron_amd.model import Tacotron2
+  key = (name, int(gate[0]), float(gate[1]))
+  if key not in _models:
+    ck = scenario_checkpoint(name, gate)
+    hp = ckpt_mod.get_hparams(ck)
+    m = Tacotron2(hp, **abi.mapping_counts(ck, hp))
+    m.load_state_dict(ck["model_state"])
+    _models[key] = m.to("cuda:0").eval()
+  return _models[key]
+
+
+def dev(a, dtype=None):
+  if a is None:
+    return None
+  t = torch.from_numpy(np.ascontiguousarray(a))
+  return t.to("cuda:0") if dtype is None else t.to("cuda:0", dtype)
+
+
+def chans(ids):
+  return [ids[k] for k in ("symbols", "stresses", "tones", "durations") if ids[k] is not None]
+
+
+@pytest.mark.parametrize("name", ["tiny", "ljs", "thchs"])
+def test_encoder_matches_oracle(name):
+  z, meta = load_golden(name)
+  om = oracle_model(meta["scenario"], meta["gate"])
+  gm = gpu_model(meta["scenario"], meta["gate"])
+  ids = golden_ids(z)
+  mem_o, pm_o = om.encode(chans(ids), ids["speakers"], None)
+  mem, pm = gm.encode([dev(c) for c in chans(ids)], dev(ids["speakers"]), None)
+  np.testing.assert_allclose(mem.cpu().numpy(), mem_o, atol=TF_TOL, rtol=0)
+  np.testing.assert_allclose(pm.cpu().numpy(), pm_o, atol=TF_TOL, rtol=0)
+
+
+@pytest.mark.parametrize("name", ["tiny_batch", "ljs_batch"])
+def test_encoder_padded_batch_matches_oracle(name):
+  z, meta = load_golden(name)
+  om = oracle_model(meta["scenario"], meta["gate"])
+  gm = gpu_model(meta["scenario"], meta["gate"])
+  ids = golden_ids(z)
+  lens = z["in_lens"]
+  mem_o, pm_o = om.encode(chans(ids), ids["speakers"], lens)
+  mem, pm = gm.encode([dev(c) for c in chans(ids)], dev(ids["speakers"]), dev(lens))
+  np.testing.assert_allclose(mem.cpu().numpy(), mem_o, atol=TF_TOL, rtol=0)
+  np.testing.assert_allclose(pm.cpu().numpy(), pm_o, atol=TF_TOL, rtol=0)
+  for b, ln in enumerate(lens):
+    assert not mem[b, ln:].any() and not pm[b, ln:].any()       # padding rows are exact zeros
+
+
+@pytest.mark.parametrize("name", ["tiny", "ljs", "thchs"])
+def test_decoder_teacher_forced_matches_reference(name):
+  """Feed the reference's own frames back (with the reference's mask stream): every frame must
+  then agree with the reference's, and the stop energies with it."""
+  z, meta = load_golden(name)
+  om = oracle_model(meta["scenario"], meta["gate"])
+  gm = gpu_model(meta["scenario"], meta["gate"])
+  ids = golden_ids(z)
+  n = meta["n_frames"]
+  mem_o, pm_o = om.encode(chans(ids), ids["speakers"], None)
+  masks = prenet_keep_masks(meta["seed"], n, om.dims.P)
+  forced = dev(z["mel"][None])
+  mel, gate, align, n_frames, reached = gm.decode(dev(mem_o), dev(pm_o), None, masks, n, forced_mel=forced)
+  assert int(n_frames[0]) == n and int(reached[0]) == 0
+  np.testing.assert_allclose(mel[0].cpu().numpy(), z["mel"], atol=TF_TOL, rtol=0)
+  np.testing.assert_allclose(gate[0].cpu().numpy(), z["gate"], atol=TF_TOL, rtol=0)
+  np.testing.assert_allclose(align[0].cpu().numpy(), z["alignments"], atol=TF_TOL, rtol=0)
+  # and with the oracle under the same forcing
+  mel_o, gate_o, align_o, _, _, _ = om.decode(mem_o, pm_o, None, masks.numpy(), n, forced_mel=z["mel"][None])
+  np.testing.assert_allclose(mel[0].cpu().numpy(), mel_o[0], atol=TF_TOL, rtol=0)
+  np.testing.assert_allclose(align[0].cpu().numpy(), align_o[0], atol=TF_TOL, rtol=0)
+
+
+@pytest.mark.parametrize("name", ["tiny", "ljs", "thchs"])
+def test_free_running_stop_frame_identical_to_reference(name):
+  z, meta = load_golden(name)
+  gm = gpu_model(meta["scenario"], meta["gate"])
+  ids = golden_ids(z)
+  torch.manual_seed(meta["seed"])
+  t = lambda a: dev(a)  # noqa: E731
+  mel, post, gate, align, reached = gm.inference(t(ids["symbols"]), t(ids["stresses"]), t(ids["tones"]),
+                                                 t(ids["durations"]), t(ids["speakers"]), meta["max_steps"])
+  n = meta["n_frames"]
+  assert mel.shape == (1, gm.dims.n_mel, n), f"stopped at {mel.shape[2]}, reference at {n}"
+  assert post.shape == mel.shape and gate.shape == (1, n, 1) and align.shape == (1, n, z["in_symbols"].shape[1])
+  assert reached is False
+  assert mel.dtype == torch.float32 and gate.dtype == torch.float32
+  np.testing.assert_allclose(mel[0].cpu().numpy(), z["mel"], atol=FREE_TOL, rtol=0)
+  np.testing.assert_allclose(post[0].cpu().numpy(), z["mel_postnet"], atol=FREE_TOL, rtol=0)
+  np.testing.assert_allclose(gate[0, :, 0].cpu().numpy(), z["gate"], atol=FREE_TOL, rtol=0)
+  np.testing.assert_allclose(align[0].cpu().numpy(), z["alignments"], atol=FREE_TOL, rtol=0)
+  margin = float(abs(gate[0, n - 1, 0]))
+  print(f"{name}: stop frame {n}, gate margin at stop {margin:.4f}")
+
+
+@pytest.mark.parametrize("name", ["tiny", "ljs"])
+def test_postnet_matches_oracle(name):
+  z, meta = load_golden(name)
+  om = oracle_model(meta["scenario"], meta["gate"])
+  gm = gpu_model(meta["scenario"], meta["gate"])
+  n = meta["n_frames"]
+  T_cap = n + 13                                 # padded columns must come out as zeros
+  mel = np.zeros((1, om.dims.n_mel, T_cap), np.float32)
+  mel[0, :, :n] = z["mel"]
+  nf = np.array([n], np.int32)
+  want = om.postnet(mel, nf)
+  got = gm.postnet(dev(mel), dev(nf)).cpu().numpy()
+  np.testing.assert_allclose(got, want, atol=2e-4, rtol=0)
+  np.testing.assert_allclose(got[0, :, :n], z["mel_postnet"], atol=2e-4, rtol=0)
+  assert not got[0, :, n:].any()
+
+
+@pytest.mark.parametrize("name", ["tiny_batch", "ljs_batch"])
+def test_padded_batch_equals_independent_reference_runs(name):
+  z, meta = load_golden(name)
+  gm = gpu_model(meta["scenario"], meta["gate"])
+  ids = golden_ids(z)
+  lens = z["in_lens"]
+  torch.manual_seed(meta["seed"])
+  mel, post, gate, align, n_frames, reached = gm.inference_batch(
+    dev(ids["symbols"]), dev(ids["stresses"]), dev(ids["tones"]), dev(ids["durations"]), dev(ids["speakers"]),
+    dev(lens), meta["max_steps"])
+  assert n_frames.cpu().tolist() == meta["n_frames"]
+  assert [bool(r) for r in reached.cpu().tolist()] == meta["reached"]
+  for b, n in enumerate(meta["n_frames"]):
+    np.testing.assert_allclose(mel[b, :, :n].cpu().numpy(), z[f"mel_{b}"], atol=FREE_TOL, rtol=0)
+    np.testing.assert_allclose(post[b, :, :n].cpu().numpy(), z[f"mel_postnet_{b}"], atol=FREE_TOL, rtol=0)
+    np.testing.assert_allclose(gate[b, :n].cpu().numpy(), z[f"gate_{b}"], atol=FREE_TOL, rtol=0)
+    np.testing.assert_allclose(align[b, :n, :lens[b]].cpu().numpy(), z[f"alignments_{b}"], atol=FREE_TOL, rtol=0)
+    assert not mel[b, :, n:].any() and not post[b, :, n:].any()
+
+
+def test_synthesizer_matches_reference_records(gate_table):
+  from tacotron_amd.synthesizer import Synthesizer
+  for name, scen in (("ljs_synth", "ljs"), ("ljs_synth_unmappable", "ljs"), ("thchs_synth", "thchs")):
+    z, meta = load_golden(name)
+    s = Synthesizer(scenario_checkpoint(scen, meta["gate"]), device="cuda:0")
+    res = s.infer(tuple(meta["symbols"]), meta["speaker"], max_decoder_steps=meta["max_steps"], seed=meta["seed"],
+                  include_stats=True)
+    assert res.sampling_rate == meta["sampling_rate"]
+    assert res.reached_max_decoder_steps == meta["reached_max_decoder_steps"]
+    assert res.mel_outputs_postnet.shape == z["mel_postnet"].shape, name
+    assert res.duration_s == meta["duration_s"]
+    assert res.inference_duration_s > 0
+    for got, key in ((res.unmappable_symbols, "unmappable_symbols"), (res.unmappable_stresses, "unmappable_stresses"),
+                     (res.unmappable_tones, "unmappable_tones"), (res.unmappable_durations, "unmappable_durations")):
+      assert (None if got is None else sorted(got)) == meta[key]
+    np.testing.assert_allclose(res.mel_outputs_postnet, z["mel_postnet"], atol=FREE_TOL, rtol=0)
+    np.testing.assert_allclose(res.mel_outputs, z["mel"], atol=FREE_TOL, rtol=0)
+    assert res.gate_outputs.shape == z["gate"].shape and res.alignments.shape == z["alignments"].shape
+    plain = s.infer(tuple(meta["symbols"]), meta["speaker"], max_decoder_steps=meta["max_steps"], seed=meta["seed"])
+    assert plain.mel_outputs is None and plain.gate_outputs is None and plain.alignments is None
+    assert np.array_equal(plain.mel_outputs_postnet, res.mel_outputs_postnet)    # deterministic
+
+
+def test_edge_cases_against_oracle(gate_table):
+  """One-symbol utterances, a single decoder step, the stop firing exactly on the last allowed step."""
+  gate = gate_table["tiny"]
+  om = oracle_model("tiny", gate)
+  gm = gpu_model("tiny", gate)
+  ck = scenario_checkpoint("tiny", gate)
+  for T_in, max_steps in ((1, 7), (2, 1), (3, 30), (40, 25)):
+    ids = scenarios.random_ids(ck, [T_in], seed=500 + T_in)
+    masks = prenet_keep_masks(9, max_steps, om.dims.P)
+    mem_o, pm_o = om.encode(chans(ids), ids["speakers"], None)
+    mel_o, gate_o, align_o, nf_o, reached_o, _ = om.decode(mem_o, pm_o, None, masks.numpy(), max_steps)
+    mem, pm = gm.encode([dev(c) for c in chans(ids)], dev(ids["speakers"]), None)
+    mel, gate_g, align, nf, reached = gm.decode(mem, pm, None, masks, max_steps)
+    assert int(nf[0]) == int(nf_o[0]) and int(reached[0]) == int(reached_o[0]), (T_in, max_steps)
+    n = int(nf_o[0])
+    np.testing.assert_allclose(mel[0, :, :n].cpu().numpy(), mel_o[0, :, :n], atol=FREE_TOL, rtol=0)
+    np.testing.assert_allclose(align[0, :n].cpu().numpy(), align_o[0, :n], atol=FREE_TOL, rtol=0)
+  # stop on the very last allowed step: allowed, and not flagged as "reached max"
+  z, meta = load_golden("tiny")
+  ids = golden_ids(z)
+  n = meta["n_frames"]
+  torch.manual_seed(meta["seed"])
+  out = gm.inference(dev(ids["symbols"]), dev(ids["stresses"]), None, None, dev(ids["speakers"]), n)
+  assert out[0].shape[2] == n and out[4] is False
+  torch.manual_seed(meta["seed"])
+  out = gm.inference(dev(ids["symbols"]), dev(ids["stresses"]), None, None, dev(ids["speakers"]), n - 1)
+  assert out[0].shape[2] == n - 1 and out[4] is True
+
+
+def test_full_size_properties(gate_table):
+  """Size-independent checks at the benchmark's extents (1000 frames of the LJS-sized model):
+  bit-reproducibility, the prefix property (fewer allowed steps = a prefix of the longer run),
+  attention weights are a distribution, reached-max flag."""
+  gate = gate_table["ljs"]
+  gm = gpu_model("ljs", gate)
+  z, meta = load_golden("ljs")
+  ids = golden_ids(z)
+  mem, pm = gm.encode([dev(c) for c in chans(ids)], dev(ids["speakers"]), None)
+  masks = prenet_keep_masks(3, 1000, gm.dims.P)
+  never = 2.0                                      # sigmoid never exceeds it: run to max_steps
+  a = gm.decode(mem, pm, None, masks, 1000, gate_threshold=never)
+  b = gm.decode(mem, pm, None, masks, 1000, gate_threshold=never)
+  assert int(a[3][0]) == 1000 and int(a[4][0]) == 1
+  assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+  c = gm.decode(mem, pm, None, masks, 300, gate_threshold=never)
+  assert torch.equal(c[0][:, :, :300], a[0][:, :, :300]) and torch.equal(c[2][:, :300], a[2][:, :300])
+  sums = a[2][0].sum(dim=1).cpu().numpy()
+  np.testing.assert_allclose(sums, np.ones_like(sums), atol=1e-5)
+  assert bool(torch.isfinite(a[0]).all())
+  post = gm.postnet(a[0], a[3])
+  assert bool(torch.isfinite(post).all())
+  us, frames = gm.last_decode_timing()
+  assert frames == 300 and us > 0
+
+
+def test_error_reporting():
+  from tacotron_amd._lib import TacoError
+  z, meta = load_golden("tiny")
+  gm = gpu_model(meta["scenario"], meta["gate"])
+  ids = golden_ids(z)
+  mem, pm = gm.encode([dev(c) for c in chans(ids)], dev(ids["speakers"]), None)
+  masks = prenet_keep_masks(1, 8, gm.dims.P)
+  with pytest.raises(ValueError):
+    gm.decode(mem, pm, None, masks[:4], 8)                 # too few mask steps
+  with pytest.raises(TacoError):
+    gm.decode(mem, pm, None, masks, 8, T_cap=4)            # max_steps beyond the output capacity
+  bad = ids["symbols"].copy()
+  bad[0, 0] = 10 ** 6
+  with pytest.raises(IndexError):
+    gm.encode([dev(bad)] + [dev(c) for c in chans(ids)[1:]], dev(ids["speakers"]), None)
+EOF

@@ -1,0 +1,97 @@
+"""The CPU oracle against the reference's outputs (tests/golden, written by tools/make_golden.py
+from the reference itself).  This is what pins the oracle; the GPU tests then compare the HIP
+path with the oracle and with the same fixtures."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tacotron_amd import scenarios
+from tacotron_amd.masks import prenet_keep_masks
+from conftest import GOLDEN, golden_ids, load_golden, oracle_model, scenario_checkpoint
+
+# fp32 arithmetic in a different summation order than the reference's BLAS: agreement to rounding
+TOL = dict(mel=2e-5, mel_postnet=5e-5, gate=5e-5, alignments=5e-5)
+
+
+def run_oracle(om, ids, max_steps, seed, forced=None):
+  masks = prenet_keep_masks(seed, max_steps, om.dims.P).numpy()
+  return om.inference(ids["symbols"], ids["stresses"], ids["tones"], ids["durations"], ids["speakers"],
+                      max_steps, masks, forced_mel=forced)
+
+
+@pytest.mark.parametrize("name", ["tiny", "ljs", "thchs"])
+def test_single_utterance_matches_reference(name):
+  z, meta = load_golden(name)
+  om = oracle_model(meta["scenario"], meta["gate"])
+  masks = prenet_keep_masks(meta["seed"], 4, om.dims.P).numpy()
+  assert np.array_equal(masks, z["masks_head"])          # RNG contract of the prenet dropouts
+  mel, post, gate, align, reached = run_oracle(om, golden_ids(z), meta["max_steps"], meta["seed"])
+  n = meta["n_frames"]
+  assert mel.shape == (1, om.dims.n_mel, n) and not reached        # identical stop frame
+  assert gate.shape == (1, n, 1) and align.shape == (1, n, z["in_symbols"].shape[1])
+  np.testing.assert_allclose(mel[0], z["mel"], atol=TOL["mel"], rtol=0)
+  np.testing.assert_allclose(post[0], z["mel_postnet"], atol=TOL["mel_postnet"], rtol=0)
+  np.testing.assert_allclose(gate[0, :, 0], z["gate"], atol=TOL["gate"], rtol=0)
+  np.testing.assert_allclose(align[0], z["alignments"], atol=TOL["alignments"], rtol=0)
+
+
+@pytest.mark.parametrize("name", ["tiny", "ljs", "thchs"])
+def test_first_steps_internal_state_matches_reference(name):
+  z, meta = load_golden(name)
+  om = oracle_model(meta["scenario"], meta["gate"])
+  ids = golden_ids(z)
+  chans = [ids[k] for k in ("symbols", "stresses", "tones", "durations") if ids[k] is not None]
+  mem, pm = om.encode(chans, ids["speakers"], None)
+  masks = prenet_keep_masks(meta["seed"], 3, om.dims.P).numpy()
+  *_, taps = om.decode(mem, pm, None, masks, 3, n_tap_steps=3, gate_threshold=2.0)
+  for key, got in om.split_taps(taps[0]).items():
+    np.testing.assert_allclose(got, z["tap_" + key], atol=1e-6, rtol=0, err_msg=key)
+
+
+def test_teacher_forcing_reproduces_reference_frames():
+  z, meta = load_golden("ljs")
+  om = oracle_model(meta["scenario"], meta["gate"])
+  n = meta["n_frames"]
+  forced = np.ascontiguousarray(z["mel"][None])
+  mel, post, gate, align, reached = run_oracle(om, golden_ids(z), n, meta["seed"], forced=forced)
+  assert mel.shape[2] == n and not reached
+  np.testing.assert_allclose(mel[0], z["mel"], atol=TOL["mel"], rtol=0)
+  np.testing.assert_allclose(gate[0, :, 0], z["gate"], atol=TOL["gate"], rtol=0)
+
+
+@pytest.mark.parametrize("name", ["tiny_batch", "ljs_batch"])
+def test_padded_batch_equals_independent_reference_runs(name):
+  z, meta = load_golden(name)
+  om = oracle_model(meta["scenario"], meta["gate"])
+  ids = golden_ids(z)
+  lens = z["in_lens"]
+  chans = [ids[k] for k in ("symbols", "stresses", "tones", "durations") if ids[k] is not None]
+  mem, pm = om.encode(chans, ids["speakers"], lens)
+  masks = prenet_keep_masks(meta["seed"], meta["max_steps"], om.dims.P).numpy()
+  mel, gate, align, n_frames, reached, _ = om.decode(mem, pm, lens, masks, meta["max_steps"])
+  post = om.postnet(mel, n_frames)
+  assert n_frames.tolist() == meta["n_frames"]
+  assert [bool(r) for r in reached] == meta["reached"]
+  for b, n in enumerate(meta["n_frames"]):
+    np.testing.assert_allclose(mel[b, :, :n], z[f"mel_{b}"], atol=TOL["mel"], rtol=0)
+    np.testing.assert_allclose(post[b, :, :n], z[f"mel_postnet_{b}"], atol=TOL["mel_postnet"], rtol=0)
+    np.testing.assert_allclose(gate[b, :n], z[f"gate_{b}"], atol=TOL["gate"], rtol=0)
+    np.testing.assert_allclose(align[b, :n, :lens[b]], z[f"alignments_{b}"], atol=TOL["alignments"], rtol=0)
+    assert not mel[b, :, n:].any() and not post[b, :, n:].any() and not align[b, :, lens[b]:].any()
+
+
+def test_generator_reproduces_committed_checkpoint(gate_table):
+  """The synthetic-checkpoint generator must give the same bytes everywhere (goldens depend on it)."""
+  stored = torch.load(os.path.join(GOLDEN, "tiny_checkpoint.pt"), map_location="cpu", weights_only=True)
+  fresh = scenario_checkpoint("tiny", gate_table["tiny"])
+  assert list(stored["model_state"].keys()) == list(fresh["model_state"].keys())
+  for k, v in stored["model_state"].items():
+    assert torch.equal(v, fresh["model_state"][k]), k
+  assert stored["hparams"] == fresh["hparams"]
+  assert dict(stored["symbol_mapping"]) == dict(fresh["symbol_mapping"])
+
+
+def test_north_wind_line_has_102_symbols():
+  assert len(scenarios.NORTH_WIND_SYMBOLS) == 102

@@ -248,4 +248,3 @@ def test_error_reporting():
   bad[0, 0] = 10 ** 6
   with pytest.raises(IndexError):
     gm.encode([dev(bad)] + [dev(c) for c in chans(ids)[1:]], dev(ids["speakers"]), None)
-EOF

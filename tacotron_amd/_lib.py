@@ -13,7 +13,8 @@ from typing import Optional
 from tacotron_amd import abi
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG_DIR, "libtaco_hip.so")
+# TACO_HIP_LIB selects another build of the same sources (e.g. the stage-stamp diagnostic build).
+LIB_PATH = os.environ.get("TACO_HIP_LIB") or os.path.join(_PKG_DIR, "libtaco_hip.so")
 CSRC_DIR = os.path.join(_PKG_DIR, "csrc")
 
 EXPORTED_SYMBOLS = (

@@ -24,12 +24,21 @@
 // enough ahead to overwrite a word another one still has to read.  Every wait is bounded by a
 // wall-clock deadline and a global abort word, so the grid always drains.
 #include "taco_device.h"
+#ifdef TACO_STAMPS
+#include <stdio.h>
+#include <vector>
+#endif
 
 namespace {
 
 constexpr int NT = TACO_DEC_THREADS;
-constexpr int CH_A = TACO_NP + TACO_NM + TACO_NA;   // 8 chunks per attention-LSTM row
-constexpr int CH_D = TACO_NA + TACO_NM + TACO_ND;   // 11 chunks per decoder-LSTM row
+// The context part of an LSTM row is held as NMF full chunks plus a 64-column tail (one register),
+// which covers memory widths up to 576 at 3 registers fewer per row than three full chunks.
+constexpr int NMF = 2;
+constexpr int CTX_TAIL0 = NMF * TACO_CHUNK;         // first column of the tail
+constexpr int TACO_M_LSTM_MAX = CTX_TAIL0 + 64;     // 576
+constexpr int CH_A = TACO_NP + NMF + TACO_NA;       // 7 full chunks per attention-LSTM row (+ tail)
+constexpr int CH_D = TACO_NA + NMF + TACO_ND;       // 10 full chunks per decoder-LSTM row (+ tail)
 constexpr int HALO = 16;                            // >= (K-1)/2 zero columns around the weights
 
 // LDS carve (float offsets, all multiples of 4)
@@ -46,8 +55,14 @@ constexpr int L_CUM = L_AW + TACO_MAX_TIN + 2 * HALO;          // cumulative wei
 constexpr int L_U = L_CUM + TACO_MAX_TIN + 2 * HALO;           // location term + processed memory [slots][128]
 constexpr int L_PMROW = L_U + TACO_E_SLOTS * TACO_MAX_A;       // processed-memory rows [slots][128]
 constexpr int L_MEMCOL = L_PMROW + TACO_E_SLOTS * TACO_MAX_A;  // memory columns [slots][1024]
-constexpr int L_W1ROW = L_MEMCOL + TACO_C_SLOTS * TACO_MAX_TIN;  // prenet layer-1 row [128]
-constexpr int L_W2ROW = L_W1ROW + 128;                         // prenet layer-2 row [256]
+constexpr int TACO_W1_ROWS = TACO_MAX_MEL;                     // n_mel capacity of the replicated prenet layer 1
+
+constexpr int L_W1T = L_MEMCOL + TACO_C_SLOTS * TACO_MAX_TIN;  // prenet layer 1, transposed [n_mel][256], in EVERY workgroup
+constexpr int P1_KPARTS = TACO_DEC_THREADS / 64;               // layer 1 is split 8 ways over its input columns
+constexpr int P1_KPER = TACO_W1_ROWS / P1_KPARTS;              // 10 input columns per part
+static_assert(P1_KPER * P1_KPARTS == TACO_W1_ROWS && TACO_NP * TACO_CHUNK == 256, "layer-1 tiling");
+constexpr int L_P1HALF = L_W1T + TACO_W1_ROWS * TACO_NP * TACO_CHUNK;   // layer-1 partial sums [8][256]
+constexpr int L_W2ROW = L_P1HALF + P1_KPARTS * TACO_NP * TACO_CHUNK;   // prenet layer-2 row [256]
 constexpr int L_QROW = L_W2ROW + TACO_NP * TACO_CHUNK;         // query row [1024]
 constexpr int L_PROJROW = L_QROW + TACO_NA * TACO_CHUNK;       // projection row [1024 + 768]
 constexpr int L_LOCCONV = L_PROJROW + (TACO_ND + TACO_NM) * TACO_CHUNK;   // [F][2][K] <= 1984
@@ -57,7 +72,10 @@ constexpr int L_CONVOUT = L_V + TACO_MAX_A;                    // location conv 
 constexpr int L_GATES = L_CONVOUT + TACO_E_SLOTS * TACO_MAX_F; // LSTM gate pre-activations [16]
 constexpr int L_RED = L_GATES + 16;                            // block-reduction scratch [32]
 constexpr int L_CELLS = L_RED + 32;                            // LSTM cell states [4 + 4]
-constexpr int L_TOTAL = L_CELLS + 8;
+constexpr int L_BIAS = L_CELLS + 8;                            // b_ih + b_hh of my rows [16 + 16]
+constexpr int L_PROJB = L_BIAS + 32;                           // bias of my projection row [4]
+constexpr int L_TOTAL = L_PROJB + 4;
+static_assert(L_TOTAL * 4 + 512 <= 160 * 1024, "decoder LDS carve exceeds a CU's 160 KiB");
 
 struct DecArgs {
   int P, M, Ra, Rd, A, F, K, n_mel, T_in, n_wg, proj_off;
@@ -74,33 +92,81 @@ struct DecArgs {
   taco_granule* gran;
   taco_dec_layout lay;
   taco_dec_ctl* ctl;
-  unsigned long long timeout_ticks;
+#ifdef TACO_STAMPS
+  unsigned long long* stamps;   // diagnostic build only: [2 workgroups][TACO_STAMP_FRAMES][TACO_STAMP_POINTS]
+#endif
 };
+
+#ifdef TACO_STAMPS
+constexpr int TACO_STAMP_FRAMES = 256, TACO_STAMP_POINTS = 12;
+#define TACO_STAMP(k)                                                                                   \
+  do {                                                                                                  \
+    if (tid == 0 && (j == 0 || j == 200) && t < TACO_STAMP_FRAMES)                                      \
+      a.stamps[((size_t)(j == 0 ? 0 : 1) * TACO_STAMP_FRAMES + t) * TACO_STAMP_POINTS + (k)] = wall_clock64(); \
+  } while (0)
+#else
+#define TACO_STAMP(k) do {} while (0)
+#endif
 
 // Dot product of NC register-resident chunks with the activation vector in LDS.  Lane l holds
 // columns 256*c + 4*l .. +3 of its row, which is exactly one 16-byte LDS read per chunk.
 template <int NC>
 __device__ __forceinline__ void dot_chunks(const float (*w0)[4], const float (*w1)[4], const float* x_lds, int lane,
-                                           float (&acc)[2][4]) {
+                                           float (&acc)[2]) {
+  float p[2][4] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     const float4 x = *reinterpret_cast<const float4*>(x_lds + c * TACO_CHUNK + lane * 4);
-    acc[0][0] = fmaf(w0[c][0], x.x, acc[0][0]);
-    acc[0][1] = fmaf(w0[c][1], x.y, acc[0][1]);
-    acc[0][2] = fmaf(w0[c][2], x.z, acc[0][2]);
-    acc[0][3] = fmaf(w0[c][3], x.w, acc[0][3]);
-    acc[1][0] = fmaf(w1[c][0], x.x, acc[1][0]);
-    acc[1][1] = fmaf(w1[c][1], x.y, acc[1][1]);
-    acc[1][2] = fmaf(w1[c][2], x.z, acc[1][2]);
-    acc[1][3] = fmaf(w1[c][3], x.w, acc[1][3]);
+    p[0][0] = fmaf(w0[c][0], x.x, p[0][0]);
+    p[0][1] = fmaf(w0[c][1], x.y, p[0][1]);
+    p[0][2] = fmaf(w0[c][2], x.z, p[0][2]);
+    p[0][3] = fmaf(w0[c][3], x.w, p[0][3]);
+    p[1][0] = fmaf(w1[c][0], x.x, p[1][0]);
+    p[1][1] = fmaf(w1[c][1], x.y, p[1][1]);
+    p[1][2] = fmaf(w1[c][2], x.z, p[1][2]);
+    p[1][3] = fmaf(w1[c][3], x.w, p[1][3]);
   }
+  acc[0] += (p[0][0] + p[0][1]) + (p[0][2] + p[0][3]);   // one live partial per row between hand-offs
+  acc[1] += (p[1][0] + p[1][1]) + (p[1][2] + p[1][3]);
 }
 
-// Strided dot of an LDS row with an LDS vector by one wave (lane-strided, then wave sum).
-__device__ __forceinline__ float wave_dot(const float* a, const float* b, int n, int lane) {
-  float acc = 0.0f;
-  for (int k = lane; k < n; k += 64) acc = fmaf(a[k], b[k], acc);
-  return taco_wave_sum(acc);
+// Per-lane partial of the dot product of an LDS row with an LDS vector, NC chunks of 256 columns:
+// lane l takes columns 256*c + 4*l .. +3 (16-byte LDS reads, all issued before the first FMA).
+// Both arrays are zero beyond the row's true length, so no bounds are checked.
+template <int NC>
+__device__ __forceinline__ float row_partial(const float* w_lds, const float* x_lds, int lane) {
+  float4 wv[NC], xv[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    wv[c] = *reinterpret_cast<const float4*>(w_lds + c * TACO_CHUNK + lane * 4);
+    xv[c] = *reinterpret_cast<const float4*>(x_lds + c * TACO_CHUNK + lane * 4);
+  }
+  float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    a0 = fmaf(wv[c].x, xv[c].x, a0);
+    a1 = fmaf(wv[c].y, xv[c].y, a1);
+    a2 = fmaf(wv[c].z, xv[c].z, a2);
+    a3 = fmaf(wv[c].w, xv[c].w, a3);
+  }
+  return (a0 + a1) + (a2 + a3);
+}
+
+// Applies the four LSTM gate non-linearities in four lanes at once and finishes the cell update:
+// lanes 4u..4u+3 of wave 0 hold gates i, f, g, o of unit u.  Returns h' in lane 4u (valid there).
+__device__ __forceinline__ float lstm_cell_lanes(const float* gates_lds, const float* bias_lds, float* cell_lds,
+                                                 int lane) {
+  const int u = lane >> 2, gi = lane & 3;
+  const float pre = gates_lds[lane & 15] + bias_lds[lane & 15];
+  const float act = gi == 2 ? taco_tanh(pre) : taco_sigmoid(pre);
+  const float ig = __shfl(act, (lane & ~3) + 0, 64);
+  const float fg = __shfl(act, (lane & ~3) + 1, 64);
+  const float gg = __shfl(act, (lane & ~3) + 2, 64);
+  const float og = __shfl(act, (lane & ~3) + 3, 64);
+  const float c = fg * cell_lds[u & 3] + ig * gg;
+  const float hv = og * taco_tanh(c);
+  if (gi == 0 && u < 4) cell_lds[u] = c;
+  return hv;
 }
 
 __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const DecArgs a) {
@@ -123,9 +189,8 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
   const bool act_a = unit < Ua && gu_a < a.Ra;       // wave-uniform
   const bool act_d = unit < Ud && gu_d < a.Rd;
 
-  float wa[2][CH_A][4];
-  float wd[2][CH_D][4];
-  float bias_a[2] = {0.0f, 0.0f}, bias_d[2] = {0.0f, 0.0f};
+  float wa[2][CH_A][4], wa_tail[2];
+  float wd[2][CH_D][4], wd_tail[2];
   {
     const int n_ih_a = a.P + a.M, n_ih_d = a.Ra + a.M;
 #pragma unroll
@@ -141,16 +206,17 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
             if (c < TACO_NP) {
               const int col = c * TACO_CHUNK + lane * 4 + e;
               if (col < a.P) v = a.att_w_ih[(size_t)ra * n_ih_a + col];
-            } else if (c < TACO_NP + TACO_NM) {
+            } else if (c < TACO_NP + NMF) {
               const int col = (c - TACO_NP) * TACO_CHUNK + lane * 4 + e;
               if (col < a.M) v = a.att_w_ih[(size_t)ra * n_ih_a + a.P + col];
             } else {
-              const int col = (c - TACO_NP - TACO_NM) * TACO_CHUNK + lane * 4 + e;
+              const int col = (c - TACO_NP - NMF) * TACO_CHUNK + lane * 4 + e;
               if (col < a.Ra) v = a.att_w_hh[(size_t)ra * a.Ra + col];
             }
           }
           wa[r][c][e] = v;
         }
+        __builtin_amdgcn_sched_barrier(0);   // keep the one-time load phase from inflating register pressure
       }
 #pragma unroll
       for (int c = 0; c < CH_D; ++c) {
@@ -161,19 +227,22 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
             if (c < TACO_NA) {
               const int col = c * TACO_CHUNK + lane * 4 + e;
               if (col < a.Ra) v = a.dec_w_ih[(size_t)rd * n_ih_d + col];
-            } else if (c < TACO_NA + TACO_NM) {
+            } else if (c < TACO_NA + NMF) {
               const int col = (c - TACO_NA) * TACO_CHUNK + lane * 4 + e;
               if (col < a.M) v = a.dec_w_ih[(size_t)rd * n_ih_d + a.Ra + col];
             } else {
-              const int col = (c - TACO_NA - TACO_NM) * TACO_CHUNK + lane * 4 + e;
+              const int col = (c - TACO_NA - NMF) * TACO_CHUNK + lane * 4 + e;
               if (col < a.Rd) v = a.dec_w_hh[(size_t)rd * a.Rd + col];
             }
           }
           wd[r][c][e] = v;
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      if (act_a) bias_a[r] = a.att_b_ih[ra] + a.att_b_hh[ra];
-      if (act_d) bias_d[r] = a.dec_b_ih[rd] + a.dec_b_hh[rd];
+      wa_tail[r] = (act_a && CTX_TAIL0 + lane < a.M) ? a.att_w_ih[(size_t)ra * n_ih_a + a.P + CTX_TAIL0 + lane] : 0.0f;
+      wd_tail[r] = (act_d && CTX_TAIL0 + lane < a.M) ? a.dec_w_ih[(size_t)rd * n_ih_d + a.Ra + CTX_TAIL0 + lane] : 0.0f;
+      if (act_a && lane == 0) lds[L_BIAS + wave * 2 + r] = a.att_b_ih[ra] + a.att_b_hh[ra];
+      if (act_d && lane == 0) lds[L_BIAS + 16 + wave * 2 + r] = a.dec_b_ih[rd] + a.dec_b_hh[rd];
     }
   }
 
@@ -182,17 +251,19 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
   const int proj_row = j - a.proj_off;
   const bool own_proj = proj_row >= 0 && proj_row <= a.n_mel;   // row n_mel is the stop-token row
   const int n_hc = a.Rd + a.M;
-  float proj_bias = 0.0f;
-  if (own_prenet) {
-    for (int k = tid; k < a.n_mel; k += NT) lds[L_W1ROW + k] = a.prenet_w1[(size_t)j * a.n_mel + k];
-    for (int k = tid; k < a.P; k += NT) lds[L_W2ROW + k] = a.prenet_w2[(size_t)j * a.P + k];
+  for (int k = tid; k < a.P * a.n_mel; k += NT) {        // every workgroup keeps all of layer 1
+    const int r = k / a.n_mel, c = k % a.n_mel;
+    lds[L_W1T + c * (TACO_NP * TACO_CHUNK) + r] = a.prenet_w1[k];
   }
+  if (own_prenet)
+    for (int k = tid; k < a.P; k += NT) lds[L_W2ROW + k] = a.prenet_w2[(size_t)j * a.P + k];
   if (own_q)
     for (int k = tid; k < a.Ra; k += NT) lds[L_QROW + k] = a.query_w[(size_t)j * a.Ra + k];
   if (own_proj) {
     const float* src = proj_row < a.n_mel ? a.proj_w + (size_t)proj_row * n_hc : a.gate_w;
-    for (int k = tid; k < n_hc; k += NT) lds[L_PROJROW + k] = src[k];
-    proj_bias = proj_row < a.n_mel ? a.proj_b[proj_row] : a.gate_b[0];
+    for (int k = tid; k < a.Rd; k += NT) lds[L_PROJROW + k] = src[k];
+    for (int k = tid; k < a.M; k += NT) lds[L_PROJROW + TACO_ND * TACO_CHUNK + k] = src[a.Rd + k];
+    if (tid == 0) lds[L_PROJB] = proj_row < a.n_mel ? a.proj_b[proj_row] : a.gate_b[0];
   }
   for (int k = tid; k < a.F * 2 * a.K; k += NT) lds[L_LOCCONV + k] = a.loc_conv_w[k];
   for (int k = tid; k < a.A * a.F; k += NT) {
@@ -204,7 +275,11 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
   for (int slot = 0; slot < TACO_E_SLOTS; ++slot) {
     const int s = j + slot * n_wg;
     if (s < len)
-      for (int k = tid; k < a.A; k += NT) lds[L_PMROW + slot * TACO_MAX_A + k] = a.pm[(size_t)s * a.A + k];
+      for (int k = tid; k < a.A; k += NT) {
+        const float v = a.pm[(size_t)s * a.A + k];
+        lds[L_PMROW + slot * TACO_MAX_A + k] = v;
+        lds[L_U + slot * TACO_MAX_A + k] = v;     // location term is zero before the first frame
+      }
   }
   for (int slot = 0; slot < TACO_C_SLOTS; ++slot) {
     const int m = j + slot * n_wg;
@@ -215,7 +290,6 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
 
   taco_wait_ctx wctx;
   wctx.abort_word = (taco_gu32*)&a.ctl->abort_code;
-  wctx.deadline = wall_clock64() + a.timeout_ticks;
   wctx.failed = 0;
 
   const bool forced = a.forced_mel != nullptr;
@@ -228,74 +302,176 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
       const taco_granule* gp = a.gran + (size_t)((t - 1) & 1) * a.lay.per_parity;
       const unsigned ep_prev = (unsigned)t;
       if (tid <= a.n_mel) {
-        const float v = taco_wait_one(gp + a.lay.mel, tid, ep_prev, wctx, 0x100u);
+        const float v = taco_wait_one(gp + a.lay.mel + (j % TACO_REP_SMALL) * a.lay.mel_cap, tid, ep_prev, wctx, 0x100u);
         if (!forced || tid == a.n_mel) lds[L_MELIN + tid] = v;
       } else if (tid >= 128 && tid < 128 + n_wg) {
-        (void)taco_wait_one(gp + a.lay.beat, tid - 128, ep_prev, wctx, 0x200u);
+        (void)taco_wait_one(gp + a.lay.beat + (j % TACO_REP_SMALL) * a.lay.beat_cap, tid - 128, ep_prev, wctx, 0x200u);
       }
       if (forced && tid < a.n_mel) lds[L_MELIN + tid] = a.forced_mel[(size_t)tid * a.T_cap + (t - 1)];
       if (__syncthreads_or(wctx.failed)) break;
       if (!forced && taco_sigmoid(lds[L_MELIN + a.n_mel]) > a.thr) { stopped = 1; break; }
     }
     if (t == a.max_steps) break;
-    wctx.deadline = wall_clock64() + a.timeout_ticks;
+      TACO_STAMP(0);
 
     const unsigned ep = (unsigned)t + 1u;
     taco_granule* g = a.gran + (size_t)(t & 1) * a.lay.per_parity;
+    // keep-bits of the two prenet dropouts: layer 1 for the row this thread finishes, layer 2 for row j
+    constexpr int PW = TACO_NP * TACO_CHUNK;
     unsigned keep1 = 0, keep2 = 0;
-    if (own_prenet) {
-      keep1 = a.masks[((size_t)t * 2 + 0) * a.P + j];
-      keep2 = a.masks[((size_t)t * 2 + 1) * a.P + j];
-    }
+    if (tid < a.P) keep1 = a.masks[((size_t)t * 2 + 0) * a.P + tid];
+    if (own_prenet) keep2 = a.masks[((size_t)t * 2 + 1) * a.P + j];
 
-    // ============ S1: prenet layer 1, row j ============
-    if (own_prenet && wave == 0) {
-      float v = wave_dot(lds + L_W1ROW, lds + L_MELIN, a.n_mel, lane);
-      v = v > 0.0f ? v : 0.0f;
-      v = keep1 ? v * 2.0f : 0.0f;
-      if (lane == 0) taco_publish(g + a.lay.p1, j, ep, v);
+    // ============ S1: prenet layer 1, ALL rows, replicated in every workgroup (20 k MACs buy one hop) ====
+    // thread = (4 adjacent rows, one of 8 slices of the input columns); rows beyond P, columns beyond
+    // n_mel are zero in LDS
+    {
+      const int rq = lane, kp = wave;
+      float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll 2
+      for (int i = 0; i < P1_KPER; ++i) {
+        const int k = kp * P1_KPER + i;
+        const float4 wv = *reinterpret_cast<const float4*>(lds + L_W1T + k * PW + rq * 4);
+        const float x = lds[L_MELIN + k];
+        acc.x = fmaf(wv.x, x, acc.x);
+        acc.y = fmaf(wv.y, x, acc.y);
+        acc.z = fmaf(wv.z, x, acc.z);
+        acc.w = fmaf(wv.w, x, acc.w);
+      }
+      *reinterpret_cast<float4*>(lds + L_P1HALF + kp * PW + rq * 4) = acc;
     }
     // meanwhile: attention-LSTM partial sums over [previous context | previous hidden]
-    float acc_a[2][4] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
+    float acc_a[2] = {0.0f, 0.0f};
     if (act_a) {
-      dot_chunks<TACO_NM>(wa[0] + TACO_NP, wa[1] + TACO_NP, lds + L_XCTX, lane, acc_a);
-      dot_chunks<TACO_NA>(wa[0] + TACO_NP + TACO_NM, wa[1] + TACO_NP + TACO_NM, lds + L_XAH, lane, acc_a);
+      dot_chunks<NMF>(wa[0] + TACO_NP, wa[1] + TACO_NP, lds + L_XCTX, lane, acc_a);
+      const float xt = lds[L_XCTX + CTX_TAIL0 + lane];
+      acc_a[0] = fmaf(wa_tail[0], xt, acc_a[0]);
+      acc_a[1] = fmaf(wa_tail[1], xt, acc_a[1]);
+      dot_chunks<TACO_NA>(wa[0] + TACO_NP + NMF, wa[1] + TACO_NP + NMF, lds + L_XAH, lane, acc_a);
     }
+    taco_lds_barrier();
+    if (tid < PW) {
+      float v = 0.0f;
+#pragma unroll
+      for (int i = 0; i < P1_KPARTS; ++i) v += lds[L_P1HALF + i * PW + tid];
+      v = v > 0.0f ? v : 0.0f;
+      lds[L_P1 + tid] = keep1 ? v * 2.0f : 0.0f;
+    }
+    taco_lds_barrier();
+    TACO_STAMP(1);
 
     // ============ S2: prenet layer 2, row j ============
-    taco_gather<NT>(g + a.lay.p1, a.P, ep, lds + L_P1, wctx, 0x300u);
+    TACO_STAMP(2);
     if (own_prenet && wave == 0) {
-      float v = wave_dot(lds + L_W2ROW, lds + L_P1, a.P, lane);
+      float v = taco_wave_sum(row_partial<TACO_NP>(lds + L_W2ROW, lds + L_P1, lane));
       v = v > 0.0f ? v : 0.0f;
       v = keep2 ? v * 2.0f : 0.0f;
-      if (lane == 0) taco_publish(g + a.lay.p, j, ep, v);
+      if (lane == 0) taco_publish_rep<TACO_REP_SMALL>(g + a.lay.p, a.lay.p_cap, j, ep, v);
     }
 
     // ============ S3: attention LSTM ============
-    taco_gather<NT>(g + a.lay.p, a.P, ep, lds + L_XP, wctx, 0x400u);
+    taco_gather<NT>(g + a.lay.p + (j % TACO_REP_SMALL) * a.lay.p_cap, a.P, ep, lds + L_XP, wctx, 0x400u);
+    TACO_STAMP(3);
     if (act_a) {
       dot_chunks<TACO_NP>(wa[0], wa[1], lds + L_XP, lane, acc_a);
-      const float s0 = taco_wave_sum((acc_a[0][0] + acc_a[0][1]) + (acc_a[0][2] + acc_a[0][3]));
-      const float s1 = taco_wave_sum((acc_a[1][0] + acc_a[1][1]) + (acc_a[1][2] + acc_a[1][3]));
+      const float s0 = taco_wave_sum(acc_a[0]);
+      const float s1 = taco_wave_sum(acc_a[1]);
       if (lane == 0) {
-        lds[L_GATES + wave * 2 + 0] = s0 + bias_a[0];
-        lds[L_GATES + wave * 2 + 1] = s1 + bias_a[1];
+        lds[L_GATES + wave * 2 + 0] = s0;
+        lds[L_GATES + wave * 2 + 1] = s1;
       }
     }
-    __syncthreads();
-    if (tid < Ua && j * Ua + tid < a.Ra) {
-      const float ig = taco_sigmoid(lds[L_GATES + tid * 4 + 0]);
-      const float fg = taco_sigmoid(lds[L_GATES + tid * 4 + 1]);
-      const float gg = tanhf(lds[L_GATES + tid * 4 + 2]);
-      const float og = taco_sigmoid(lds[L_GATES + tid * 4 + 3]);
-      const float c = fg * lds[L_CELLS + tid] + ig * gg;
-      lds[L_CELLS + tid] = c;
-      taco_publish(g + a.lay.ah, j * Ua + tid, ep, og * tanhf(c));
+    taco_lds_barrier();
+    if (wave == 0) {
+      const float hv = lstm_cell_lanes(lds + L_GATES, lds + L_BIAS, lds + L_CELLS, lane);
+      const int u = lane >> 2;
+      if ((lane & 3) == 0 && u < Ua && j * Ua + u < a.Ra) taco_publish_rep<TACO_REP_BIG>(g + a.lay.ah, a.lay.ah_cap, j * Ua + u, ep, hv);
     }
-    // meanwhile: decoder-LSTM partial over the previous decoder hidden state ...
-    float acc_d[2][4] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
-    if (act_d) dot_chunks<TACO_ND>(wd[0] + TACO_NA + TACO_NM, wd[1] + TACO_NA + TACO_NM, lds + L_XDH, lane, acc_d);
-    // ... and the location features of my positions (they use the previous frame's weights)
+    // meanwhile: decoder-LSTM partial over the previous decoder hidden state
+    float acc_d[2] = {0.0f, 0.0f};
+    if (act_d) dot_chunks<TACO_ND>(wd[0] + TACO_NA + NMF, wd[1] + TACO_NA + NMF, lds + L_XDH, lane, acc_d);
+
+    // ============ S4: query projection, row j ============
+    TACO_STAMP(4);
+    taco_gather<NT>(g + a.lay.ah + (j % TACO_REP_BIG) * a.lay.ah_cap, a.Ra, ep, lds + L_XAH, wctx, 0x500u);
+    TACO_STAMP(5);
+    if (own_q && wave == 0) {
+      const float v = taco_wave_sum(row_partial<TACO_NA>(lds + L_QROW, lds + L_XAH, lane));
+      if (lane == 0) taco_publish_rep<TACO_REP_SMALL>(g + a.lay.q, a.lay.q_cap, j, ep, v);
+    }
+    if (act_d) dot_chunks<TACO_NA>(wd[0], wd[1], lds + L_XAH, lane, acc_d);
+
+    // ============ S5: energies of my positions ============
+    taco_gather<NT>(g + a.lay.q + (j % TACO_REP_SMALL) * a.lay.q_cap, a.A, ep, lds + L_Q, wctx, 0x600u);
+    TACO_STAMP(6);
+    if (wave < TACO_E_SLOTS) {
+      const int s = j + wave * n_wg;
+      if (s < len) {
+        float acc = 0.0f;
+        for (int aa = lane; aa < a.A; aa += 64)
+          acc = fmaf(lds[L_V + aa], taco_tanh(lds[L_Q + aa] + lds[L_U + wave * TACO_MAX_A + aa]), acc);
+        acc = taco_wave_sum(acc);
+        if (lane == 0) taco_publish_rep<TACO_REP_SMALL>(g + a.lay.e, a.lay.e_cap, s, ep, acc);
+      }
+    }
+
+    // ============ S6: softmax over all positions (every workgroup), context columns of mine ============
+    taco_gather<NT>(g + a.lay.e + (j % TACO_REP_SMALL) * a.lay.e_cap, len, ep, lds + L_EW, wctx, 0x700u);
+    TACO_STAMP(7);
+    {
+      constexpr int PER = TACO_MAX_TIN / NT;   // positions per thread
+      float ev[PER], ex[PER];
+      float wm = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const int s = tid + i * NT;
+        ev[i] = s < len ? lds[L_EW + s] : -INFINITY;
+        wm = fmaxf(wm, ev[i]);
+      }
+      wm = taco_wave_max(wm);
+      if (lane == 0) lds[L_RED + wave] = wm;
+      taco_lds_barrier();
+      float mx = lds[L_RED];
+#pragma unroll
+      for (int i = 1; i < NT / 64; ++i) mx = fmaxf(mx, lds[L_RED + i]);
+      float ws = 0.0f;
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const int s = tid + i * NT;
+        ex[i] = s < len ? taco_exp(ev[i] - mx) : 0.0f;
+        ws += ex[i];
+      }
+      ws = taco_wave_sum(ws);
+      if (lane == 0) lds[L_RED + 16 + wave] = ws;
+      taco_lds_barrier();
+      float sum = 0.0f;
+#pragma unroll
+      for (int i = 0; i < NT / 64; ++i) sum += lds[L_RED + 16 + i];
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const int s = tid + i * NT;
+        if (s < len) {
+          const float wgt = ex[i] / sum;
+          lds[L_AW + HALO + s] = wgt;
+          lds[L_CUM + HALO + s] += wgt;
+          if (j == 0 && a.align) a.align[(size_t)t * a.T_in + s] = wgt;
+        }
+      }
+      taco_lds_barrier();
+    }
+    if (wave < TACO_C_SLOTS) {
+      const int m = j + wave * n_wg;
+      if (m < a.M) {
+        float acc = 0.0f;
+        for (int s = lane; s < len; s += 64)
+          acc = fmaf(lds[L_AW + HALO + s], lds[L_MEMCOL + wave * TACO_MAX_TIN + s], acc);
+        acc = taco_wave_sum(acc);
+        if (lane == 0) taco_publish_rep<TACO_REP_CTX>(g + a.lay.ctx, a.lay.ctx_cap, m, ep, acc);
+      }
+    }
+
+    // while the context travels: location features of my positions for the NEXT frame (they need
+    // only this frame's weights and cumulative weights, which are final now)
     if (tid < 256) {
       const int f = tid >> 3, part = tid & 7;
       for (int slot = 0; slot < TACO_E_SLOTS; ++slot) {
@@ -316,7 +492,7 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
         if (part == 0 && f < a.F) lds[L_CONVOUT + slot * TACO_MAX_F + f] = acc;
       }
     }
-    __syncthreads();
+    taco_lds_barrier();
     if (tid < TACO_E_SLOTS * TACO_MAX_A) {
       const int slot = tid >> 7, aa = tid & 127;
       const int s = j + slot * n_wg;
@@ -328,115 +504,44 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
       }
     }
 
-    // ============ S4: query projection, row j ============
-    taco_gather<NT>(g + a.lay.ah, a.Ra, ep, lds + L_XAH, wctx, 0x500u);
-    if (own_q && wave == 0) {
-      const float v = wave_dot(lds + L_QROW, lds + L_XAH, a.Ra, lane);
-      if (lane == 0) taco_publish(g + a.lay.q, j, ep, v);
-    }
-    if (act_d) dot_chunks<TACO_NA>(wd[0], wd[1], lds + L_XAH, lane, acc_d);
-
-    // ============ S5: energies of my positions ============
-    taco_gather<NT>(g + a.lay.q, a.A, ep, lds + L_Q, wctx, 0x600u);
-    if (wave < TACO_E_SLOTS) {
-      const int s = j + wave * n_wg;
-      if (s < len) {
-        float acc = 0.0f;
-        for (int aa = lane; aa < a.A; aa += 64)
-          acc = fmaf(lds[L_V + aa], tanhf(lds[L_Q + aa] + lds[L_U + wave * TACO_MAX_A + aa]), acc);
-        acc = taco_wave_sum(acc);
-        if (lane == 0) taco_publish(g + a.lay.e, s, ep, acc);
-      }
-    }
-
-    // ============ S6: softmax over all positions (every workgroup), context columns of mine ============
-    taco_gather<NT>(g + a.lay.e, len, ep, lds + L_EW, wctx, 0x700u);
-    {
-      constexpr int PER = TACO_MAX_TIN / NT;   // positions per thread
-      float ev[PER], ex[PER];
-      float wm = -INFINITY;
-#pragma unroll
-      for (int i = 0; i < PER; ++i) {
-        const int s = tid + i * NT;
-        ev[i] = s < len ? lds[L_EW + s] : -INFINITY;
-        wm = fmaxf(wm, ev[i]);
-      }
-      wm = taco_wave_max(wm);
-      if (lane == 0) lds[L_RED + wave] = wm;
-      __syncthreads();
-      float mx = lds[L_RED];
-#pragma unroll
-      for (int i = 1; i < NT / 64; ++i) mx = fmaxf(mx, lds[L_RED + i]);
-      float ws = 0.0f;
-#pragma unroll
-      for (int i = 0; i < PER; ++i) {
-        const int s = tid + i * NT;
-        ex[i] = s < len ? expf(ev[i] - mx) : 0.0f;
-        ws += ex[i];
-      }
-      ws = taco_wave_sum(ws);
-      if (lane == 0) lds[L_RED + 16 + wave] = ws;
-      __syncthreads();
-      float sum = 0.0f;
-#pragma unroll
-      for (int i = 0; i < NT / 64; ++i) sum += lds[L_RED + 16 + i];
-#pragma unroll
-      for (int i = 0; i < PER; ++i) {
-        const int s = tid + i * NT;
-        if (s < len) {
-          const float wgt = ex[i] / sum;
-          lds[L_AW + HALO + s] = wgt;
-          lds[L_CUM + HALO + s] += wgt;
-          if (j == 0 && a.align) a.align[(size_t)t * a.T_in + s] = wgt;
-        }
-      }
-      __syncthreads();
-    }
-    if (wave < TACO_C_SLOTS) {
-      const int m = j + wave * n_wg;
-      if (m < a.M) {
-        float acc = 0.0f;
-        for (int s = lane; s < len; s += 64)
-          acc = fmaf(lds[L_AW + HALO + s], lds[L_MEMCOL + wave * TACO_MAX_TIN + s], acc);
-        acc = taco_wave_sum(acc);
-        if (lane == 0) taco_publish(g + a.lay.ctx, m, ep, acc);
-      }
-    }
-
     // ============ S7: decoder LSTM ============
-    taco_gather<NT>(g + a.lay.ctx, a.M, ep, lds + L_XCTX, wctx, 0x800u);
-    if (tid == 0) taco_publish(g + a.lay.beat, j, ep, 0.0f);   // heartbeat: frame t's inputs consumed
+    TACO_STAMP(8);
+    taco_gather<NT>(g + a.lay.ctx + (j % TACO_REP_CTX) * a.lay.ctx_cap, a.M, ep, lds + L_XCTX, wctx, 0x800u);
+    TACO_STAMP(9);
     if (act_d) {
-      dot_chunks<TACO_NM>(wd[0] + TACO_NA, wd[1] + TACO_NA, lds + L_XCTX, lane, acc_d);
-      const float s0 = taco_wave_sum((acc_d[0][0] + acc_d[0][1]) + (acc_d[0][2] + acc_d[0][3]));
-      const float s1 = taco_wave_sum((acc_d[1][0] + acc_d[1][1]) + (acc_d[1][2] + acc_d[1][3]));
+      dot_chunks<NMF>(wd[0] + TACO_NA, wd[1] + TACO_NA, lds + L_XCTX, lane, acc_d);
+      const float xt = lds[L_XCTX + CTX_TAIL0 + lane];
+      acc_d[0] = fmaf(wd_tail[0], xt, acc_d[0]);
+      acc_d[1] = fmaf(wd_tail[1], xt, acc_d[1]);
+      const float s0 = taco_wave_sum(acc_d[0]);
+      const float s1 = taco_wave_sum(acc_d[1]);
       if (lane == 0) {
-        lds[L_GATES + wave * 2 + 0] = s0 + bias_d[0];
-        lds[L_GATES + wave * 2 + 1] = s1 + bias_d[1];
+        lds[L_GATES + wave * 2 + 0] = s0;
+        lds[L_GATES + wave * 2 + 1] = s1;
       }
     }
-    __syncthreads();
-    if (tid < Ud && j * Ud + tid < a.Rd) {
-      const float ig = taco_sigmoid(lds[L_GATES + tid * 4 + 0]);
-      const float fg = taco_sigmoid(lds[L_GATES + tid * 4 + 1]);
-      const float gg = tanhf(lds[L_GATES + tid * 4 + 2]);
-      const float og = taco_sigmoid(lds[L_GATES + tid * 4 + 3]);
-      const float c = fg * lds[L_CELLS + 4 + tid] + ig * gg;
-      lds[L_CELLS + 4 + tid] = c;
-      taco_publish(g + a.lay.dh, j * Ud + tid, ep, og * tanhf(c));
+    taco_lds_barrier();
+    if (wave == 0) {
+      const float hv = lstm_cell_lanes(lds + L_GATES, lds + L_BIAS + 16, lds + L_CELLS + 4, lane);
+      const int u = lane >> 2;
+      if ((lane & 3) == 0 && u < Ud && j * Ud + u < a.Rd) taco_publish_rep<TACO_REP_BIG>(g + a.lay.dh, a.lay.dh_cap, j * Ud + u, ep, hv);
     }
     // meanwhile: context half of my projection row
     float acc_p = 0.0f;
-    if (own_proj && wave == 1)
-      for (int k = lane; k < a.M; k += 64) acc_p = fmaf(lds[L_PROJROW + a.Rd + k], lds[L_XCTX + k], acc_p);
+    if (own_proj && wave == 1) acc_p = row_partial<TACO_NM>(lds + L_PROJROW + TACO_ND * TACO_CHUNK, lds + L_XCTX, lane);
 
     // ============ S8: mel / stop-token projection, row proj_row ============
-    taco_gather<NT>(g + a.lay.dh, a.Rd, ep, lds + L_XDH, wctx, 0x900u);
+    TACO_STAMP(10);
+    taco_gather<NT>(g + a.lay.dh + (j % TACO_REP_BIG) * a.lay.dh_cap, a.Rd, ep, lds + L_XDH, wctx, 0x900u);
+    TACO_STAMP(11);
+    // heartbeat: every hand-off vector of frame t except the frame output has been consumed here
+    // (published by a wave that does not poll at the frame boundary)
+    if (tid == NT - 64) taco_publish_rep<TACO_REP_SMALL>(g + a.lay.beat, a.lay.beat_cap, j, ep, 0.0f);
     if (own_proj && wave == 1) {
-      for (int k = lane; k < a.Rd; k += 64) acc_p = fmaf(lds[L_PROJROW + k], lds[L_XDH + k], acc_p);
-      const float v = taco_wave_sum(acc_p) + proj_bias;
+      acc_p += row_partial<TACO_ND>(lds + L_PROJROW, lds + L_XDH, lane);
+      const float v = taco_wave_sum(acc_p) + lds[L_PROJB];
       if (lane == 0) {
-        taco_publish(g + a.lay.mel, proj_row, ep, v);
+        taco_publish_rep<TACO_REP_SMALL>(g + a.lay.mel, a.lay.mel_cap, proj_row, ep, v);
         if (proj_row < a.n_mel) a.mel[(size_t)proj_row * a.T_cap + t] = v;
         else a.gate[t] = v;
       }
@@ -455,20 +560,20 @@ size_t taco_decoder_lds_bytes() { return (size_t)L_TOTAL * sizeof(float); }
 
 static void fill_layout(taco_dec_layout& lay, int n_wg) {
   int off = 0;
-  auto take = [&](int n) {
+  auto take = [&](int n, int reps, int32_t& cap) {
     const int at = off;
-    off += (n + 15) / 16 * 16;   // 128-byte aligned vectors
+    cap = (n + 15) / 16 * 16;    // 128-byte aligned replicas
+    off += cap * reps;
     return at;
   };
-  lay.p1 = take(TACO_NP * TACO_CHUNK);
-  lay.p = take(TACO_NP * TACO_CHUNK);
-  lay.ah = take(TACO_NA * TACO_CHUNK);
-  lay.q = take(TACO_MAX_A);
-  lay.e = take(TACO_MAX_TIN);
-  lay.ctx = take(TACO_NM * TACO_CHUNK);
-  lay.dh = take(TACO_ND * TACO_CHUNK);
-  lay.mel = take(128);
-  lay.beat = take(n_wg);
+  lay.p = take(TACO_NP * TACO_CHUNK, TACO_REP_SMALL, lay.p_cap);
+  lay.ah = take(TACO_NA * TACO_CHUNK, TACO_REP_BIG, lay.ah_cap);
+  lay.q = take(TACO_MAX_A, TACO_REP_SMALL, lay.q_cap);
+  lay.e = take(TACO_MAX_TIN, TACO_REP_SMALL, lay.e_cap);
+  lay.ctx = take(TACO_NM * TACO_CHUNK, TACO_REP_CTX, lay.ctx_cap);
+  lay.dh = take(TACO_ND * TACO_CHUNK, TACO_REP_BIG, lay.dh_cap);
+  lay.mel = take(128, TACO_REP_SMALL, lay.mel_cap);
+  lay.beat = take(n_wg, TACO_REP_SMALL, lay.beat_cap);
   lay.per_parity = off;
 }
 
@@ -480,7 +585,7 @@ size_t taco_decoder_granules(int n_wg) {
 
 int taco_decoder_check_dims(const taco_dims& d, int n_wg) {
   if (d.P > TACO_NP * TACO_CHUNK || d.P > n_wg) TACO_FAIL(TACO_EINVAL, "prenet_dim %d exceeds the decoder kernel's capacity %d", d.P, TACO_NP * TACO_CHUNK < n_wg ? TACO_NP * TACO_CHUNK : n_wg);
-  if (d.M > TACO_NM * TACO_CHUNK || d.M > TACO_C_SLOTS * n_wg) TACO_FAIL(TACO_EINVAL, "memory width %d exceeds the decoder kernel's capacity %d", d.M, TACO_NM * TACO_CHUNK);
+  if (d.M > TACO_M_LSTM_MAX || d.M > TACO_C_SLOTS * n_wg) TACO_FAIL(TACO_EINVAL, "memory width %d exceeds the decoder kernel's capacity %d", d.M, TACO_M_LSTM_MAX);
   if (d.R_a > TACO_NA * TACO_CHUNK || d.R_a > TACO_UNITS_PER_WG * n_wg) TACO_FAIL(TACO_EINVAL, "attention_rnn_dim %d exceeds the decoder kernel's capacity", d.R_a);
   if (d.R_d > TACO_ND * TACO_CHUNK || d.R_d > TACO_UNITS_PER_WG * n_wg) TACO_FAIL(TACO_EINVAL, "decoder_rnn_dim %d exceeds the decoder kernel's capacity", d.R_d);
   if (d.A > TACO_MAX_A || d.A > n_wg) TACO_FAIL(TACO_EINVAL, "attention_dim %d exceeds the decoder kernel's capacity %d", d.A, TACO_MAX_A);
@@ -512,7 +617,6 @@ int taco_launch_decoder(taco_handle h, const float* memory, const float* pm, int
   a.memory = memory; a.pm = pm; a.masks = masks; a.T_cap = T_cap; a.max_steps = max_steps; a.thr = thr;
   a.forced_mel = forced_mel; a.mel = mel; a.gate = gate; a.align = align;
   a.gran = h->dec_gran; a.lay = h->dec_lay; a.ctl = h->dec_ctl;
-  a.timeout_ticks = 20000000ull;   // 0.2 s of the 100 MHz wall clock per frame
 
   const size_t gran_bytes = (size_t)h->dec_lay.per_parity * 2 * sizeof(taco_granule);
   TACO_HIP(hipMemsetAsync(h->dec_gran, 0, gran_bytes, s));
@@ -521,6 +625,13 @@ int taco_launch_decoder(taco_handle h, const float* memory, const float* pm, int
   TACO_HIP(hipMemsetAsync(gate, 0, sizeof(float) * (size_t)T_cap, s));
   if (align) TACO_HIP(hipMemsetAsync(align, 0, sizeof(float) * (size_t)T_cap * T_in, s));
 
+#ifdef TACO_STAMPS
+  static unsigned long long* stamps_dev = nullptr;
+  const size_t stamp_count = (size_t)2 * TACO_STAMP_FRAMES * TACO_STAMP_POINTS;
+  if (!stamps_dev) TACO_HIP(hipMalloc((void**)&stamps_dev, stamp_count * 8));
+  TACO_HIP(hipMemsetAsync(stamps_dev, 0, stamp_count * 8, s));
+  a.stamps = stamps_dev;
+#endif
   TACO_HIP(hipEventRecord(h->ev_start, s));
   hipLaunchKernelGGL(taco_decoder_kernel, dim3(n_wg), dim3(NT), taco_decoder_lds_bytes(), s, a);
   TACO_HIP(hipGetLastError());
@@ -533,6 +644,30 @@ int taco_launch_decoder(taco_handle h, const float* memory, const float* pm, int
   if (h->dec_ctl_host->abort_code != 0)
     TACO_FAIL(TACO_ETIMEDOUT, "decoder hand-off wait gave up (code %u, info 0x%x) after %u frames",
               h->dec_ctl_host->abort_code, h->dec_ctl_host->abort_info, h->dec_ctl_host->n_frames);
+#ifdef TACO_STAMPS
+  {
+    std::vector<unsigned long long> st(stamp_count);
+    TACO_HIP(hipMemcpy(st.data(), stamps_dev, stamp_count * 8, hipMemcpyDeviceToHost));
+    const int nfr = (int)h->dec_ctl_host->n_frames < TACO_STAMP_FRAMES ? (int)h->dec_ctl_host->n_frames : TACO_STAMP_FRAMES;
+    static const char* names[TACO_STAMP_POINTS] = {"frame top done", "S1 publish p1 + attn partial", "gather p1", "S2 + gather p",
+        "S3 attn LSTM + loc features", "gather ah", "S4 q + gather q", "S5 energies + gather e", "S6 softmax + ctx",
+        "gather ctx", "S7 dec LSTM", "gather dh"};
+    for (int wg = 0; wg < 2 && nfr > 8; ++wg) {
+      double acc[TACO_STAMP_POINTS + 1] = {0};
+      int cnt = 0;
+      for (int t = 4; t + 1 < nfr; ++t, ++cnt) {
+        const unsigned long long* r = &st[((size_t)wg * TACO_STAMP_FRAMES + t) * TACO_STAMP_POINTS];
+        const unsigned long long* nx = &st[((size_t)wg * TACO_STAMP_FRAMES + t + 1) * TACO_STAMP_POINTS];
+        for (int k = 1; k < TACO_STAMP_POINTS; ++k) acc[k] += (double)(r[k] - r[k - 1]) * 0.01;
+        acc[TACO_STAMP_POINTS] += (double)(nx[0] - r[TACO_STAMP_POINTS - 1]) * 0.01;
+      }
+      fprintf(stderr, "[taco stamps] workgroup %s, mean over %d frames (us):\n", wg == 0 ? "0" : "200", cnt);
+      double tot = 0;
+      for (int k = 1; k < TACO_STAMP_POINTS; ++k) { fprintf(stderr, "  %-32s %7.2f\n", names[k], acc[k] / cnt); tot += acc[k] / cnt; }
+      fprintf(stderr, "  %-32s %7.2f\n  total %7.2f\n", "S8 proj + frame top (mel, beats)", acc[TACO_STAMP_POINTS] / cnt, tot + acc[TACO_STAMP_POINTS] / cnt);
+    }
+  }
+#endif
   const int32_t nf = (int32_t)h->dec_ctl_host->n_frames;
   const uint8_t rm = (uint8_t)h->dec_ctl_host->reached_max;
   h->last_frames = nf;

@@ -13,27 +13,51 @@ typedef __attribute__((address_space(1))) unsigned int taco_gu32;
 // Abort codes written to the control block.
 #define TACO_ABORT_TIMEOUT 1u
 
-__device__ __forceinline__ float taco_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+// exp / sigmoid / tanh on the hardware exp2 and reciprocal (v_exp_f32, v_rcp_f32: 1 ulp each).  The
+// product x*log2(e) is carried in two floats so the exponent argument is exact to ~2^-48; results
+// agree with libm's to about 2 ulp (tanh: 2e-7 absolute), far inside the parity tolerance, at a
+// fraction of the instruction count of the library calls.
+__device__ __forceinline__ float taco_exp(float x) {
+  const float hi = x * 1.44269502e+0f;
+  float lo = fmaf(x, 1.44269502e+0f, -hi);
+  lo = fmaf(x, 1.92596299e-8f, lo);
+  const float r = __builtin_amdgcn_exp2f(hi);
+  return fmaf(r, lo * 6.93147182e-1f, r);
+}
+__device__ __forceinline__ float taco_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + taco_exp(-x)); }
+__device__ __forceinline__ float taco_tanh(float x) {
+  const float ax = fminf(fabsf(x), 15.0f);
+  const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(taco_exp(2.0f * ax) + 1.0f);
+  return copysignf(t, x);
+}
 
-// Sum over the 64 lanes of a wave; every lane receives the total.
-#if defined(TACO_DPP_REDUCE)
+// Wave-wide (64-lane) reductions; every lane receives the result.  The default form rotates and
+// combines inside each row of 16 lanes with DPP (row_ror:8,4,2,1 - no LDS crossbar traffic) and then
+// combines the four row results read with v_readlane; -DTACO_SHFL_REDUCE selects the plain
+// __shfl_xor butterfly instead (same result up to the association order of the additions).
+#if !defined(TACO_SHFL_REDUCE)
 template <int CTRL>
 __device__ __forceinline__ float taco_dpp_rot(float v) {
   return __builtin_bit_cast(
       float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
 }
+__device__ __forceinline__ float taco_lane_value(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
 __device__ __forceinline__ float taco_wave_sum(float v) {
-  // rotate-and-add inside each row of 16 lanes (row_ror:8,4,2,1), then add the four row totals
   v += taco_dpp_rot<0x128>(v);
   v += taco_dpp_rot<0x124>(v);
   v += taco_dpp_rot<0x122>(v);
   v += taco_dpp_rot<0x121>(v);
-  const int vi = __builtin_bit_cast(int, v);
-  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 0));
-  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 16));
-  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 32));
-  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 48));
-  return (r0 + r1) + (r2 + r3);
+  return (taco_lane_value(v, 0) + taco_lane_value(v, 16)) + (taco_lane_value(v, 32) + taco_lane_value(v, 48));
+}
+__device__ __forceinline__ float taco_wave_max(float v) {
+  v = fmaxf(v, taco_dpp_rot<0x128>(v));
+  v = fmaxf(v, taco_dpp_rot<0x124>(v));
+  v = fmaxf(v, taco_dpp_rot<0x122>(v));
+  v = fmaxf(v, taco_dpp_rot<0x121>(v));
+  return fmaxf(fmaxf(taco_lane_value(v, 0), taco_lane_value(v, 16)),
+               fmaxf(taco_lane_value(v, 32), taco_lane_value(v, 48)));
 }
 #else
 __device__ __forceinline__ float taco_wave_sum(float v) {
@@ -41,13 +65,12 @@ __device__ __forceinline__ float taco_wave_sum(float v) {
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
   return v;
 }
-#endif
-
 __device__ __forceinline__ float taco_wave_max(float v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
   return v;
 }
+#endif
 
 // ---- hand-off: one 8-byte word carries {epoch, fp32}; the data is its own flag -------------------
 __device__ __forceinline__ void taco_publish(taco_granule* base, int idx, unsigned epoch, float value) {
@@ -55,14 +78,25 @@ __device__ __forceinline__ void taco_publish(taco_granule* base, int idx, unsign
   __hip_atomic_store((taco_ggran*)base + idx, word, TACO_RLX_AGENT);
 }
 
+// Publishes one value to all R replicas of a vector (replica stride `cap` granules).
+template <int R>
+__device__ __forceinline__ void taco_publish_rep(taco_granule* base, int cap, int idx, unsigned epoch, float value) {
+  const taco_granule word = ((taco_granule)epoch << 32) | (taco_granule)__float_as_uint(value);
+#pragma unroll
+  for (int r = 0; r < R; ++r) __hip_atomic_store((taco_ggran*)base + (size_t)r * cap + idx, word, TACO_RLX_AGENT);
+}
+
 struct taco_wait_ctx {
   taco_gu32* abort_word;     // global abort flag
-  unsigned long long deadline;  // wall_clock64() value after which waits give up
   int failed;                // sticky, per thread
 };
 
+// A wait gives up after this many polls (each poll is a round trip to memory of roughly a
+// microsecond, so about a quarter of a second) or as soon as another wave has raised the abort flag.
+constexpr unsigned TACO_SPIN_LIMIT = 1u << 18;
+
 // Spins until granule idx carries `epoch`; returns the payload.  Gives up when the global abort
-// flag is raised or the deadline passes (then raises the flag itself), so the grid always drains.
+// flag is raised or the poll budget is spent (then raises the flag itself), so the grid always drains.
 __device__ __forceinline__ float taco_wait_one(const taco_granule* base, int idx, unsigned epoch,
                                                taco_wait_ctx& ctx, unsigned info) {
   const taco_ggran* g = (const taco_ggran*)base + idx;
@@ -73,7 +107,7 @@ __device__ __forceinline__ float taco_wait_one(const taco_granule* base, int idx
     __builtin_amdgcn_s_sleep(1);
     if ((++spins & 255u) == 0u) {
       if (__hip_atomic_load(ctx.abort_word, TACO_RLX_AGENT) != 0u) { ctx.failed = 1; break; }
-      if (wall_clock64() > ctx.deadline) {
+      if (spins >= TACO_SPIN_LIMIT) {
         __hip_atomic_store(ctx.abort_word, TACO_ABORT_TIMEOUT, TACO_RLX_AGENT);
         __hip_atomic_store(ctx.abort_word + 1, info, TACO_RLX_AGENT);
         ctx.failed = 1;
@@ -85,10 +119,19 @@ __device__ __forceinline__ float taco_wait_one(const taco_granule* base, int idx
   return __uint_as_float((unsigned)word);
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding
+// global store of the wave (vmcnt(0)); after a publish that is a write-through store on its way to
+// memory, and nothing here needs to wait for it: granule stores are consumed by other workgroups.
+__device__ __forceinline__ void taco_lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // All threads of the workgroup collect granules [0, n) into LDS and synchronise.
 template <int NTHREADS>
 __device__ __forceinline__ void taco_gather(const taco_granule* base, int n, unsigned epoch, float* lds_dst,
                                             taco_wait_ctx& ctx, unsigned info) {
   for (int idx = threadIdx.x; idx < n; idx += NTHREADS) lds_dst[idx] = taco_wait_one(base, idx, epoch, ctx, info);
-  __syncthreads();
+  taco_lds_barrier();
 }

@@ -29,19 +29,25 @@ constexpr int TACO_ND = 4;    // decoder-LSTM hidden chunks     -> R_d <= 1024
 constexpr int TACO_MAX_A = 128;
 constexpr int TACO_MAX_F = 32;
 constexpr int TACO_MAX_K = 31;
-constexpr int TACO_MAX_MEL = 127;           // n_mel + 1 gate row <= 128
-constexpr int TACO_MAX_TIN = 1024;          // symbols per utterance
+constexpr int TACO_MAX_MEL = 80;            // prenet layer 1 is replicated in every workgroup's LDS
+constexpr int TACO_MAX_TIN = 512;           // symbols per utterance
 constexpr int TACO_DEC_THREADS = 512;       // 8 waves: two LSTM gate rows per wave
 constexpr int TACO_UNITS_PER_WG = 4;        // 4 hidden units x 4 gates = 16 rows per LSTM per workgroup
-constexpr int TACO_E_SLOTS = 4;             // energy positions per workgroup = ceil(T_in / n_wg)
+constexpr int TACO_E_SLOTS = 2;             // energy positions per workgroup = ceil(T_in / n_wg)
 constexpr int TACO_C_SLOTS = 3;             // context columns per workgroup  = ceil(M / n_wg)
 
 // Tagged 8-byte hand-off word: high half = epoch (frame + 1), low half = fp32 payload.
 typedef unsigned long long taco_granule;
 
-// Granule vectors of the decoder, in units of granules from the base; two parities each.
+// Granule vectors of the decoder, in units of granules from the base; two parities each.  A vector
+// is stored in several identical replicas (producers write all, consumer workgroup j polls replica
+// j % R): 256 pollers on the few cache lines of a short vector is what limits a hand-off's latency.
+constexpr int TACO_REP_SMALL = 8;   // p, q, e, mel, heartbeats (<= 512 granules)
+constexpr int TACO_REP_CTX = 4;     // context (<= 768 granules)
+constexpr int TACO_REP_BIG = 2;     // LSTM hidden states (1024 granules)
 struct taco_dec_layout {
-  int32_t p1, p, ah, q, e, ctx, dh, mel, beat;   // offsets
+  int32_t p, ah, q, e, ctx, dh, mel, beat;       // offsets of replica 0
+  int32_t p_cap, ah_cap, q_cap, e_cap, ctx_cap, dh_cap, mel_cap, beat_cap;   // replica strides
   int32_t per_parity;                            // granules per parity block
 };
 

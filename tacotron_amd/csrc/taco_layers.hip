@@ -150,7 +150,6 @@ struct EncLstmArgs {
   int H, T, M, n_wg_dir;
   taco_granule* gran;     // [2 dirs][2 parities][512]
   uint32_t* ctl;
-  unsigned long long timeout_ticks;
 };
 
 __global__ __launch_bounds__(1024) void taco_enc_lstm_kernel(const EncLstmArgs a) {
@@ -179,7 +178,6 @@ __global__ __launch_bounds__(1024) void taco_enc_lstm_kernel(const EncLstmArgs a
 
   taco_wait_ctx wctx;
   wctx.abort_word = (taco_gu32*)a.ctl;
-  wctx.deadline = wall_clock64() + a.timeout_ticks;
   wctx.failed = 0;
   taco_granule* gdir = a.gran + (size_t)dir * 2 * 512;
   const float* gx = a.gx + (size_t)dir * 4 * a.H * a.T;
@@ -191,8 +189,7 @@ __global__ __launch_bounds__(1024) void taco_enc_lstm_kernel(const EncLstmArgs a
     if (s > 0) {
       taco_gather<1024>(gdir + (size_t)((s - 1) & 1) * 512, a.H, (unsigned)s, xh, wctx, 0xE00u);
       if (__syncthreads_or(wctx.failed)) break;
-      wctx.deadline = wall_clock64() + a.timeout_ticks;
-    }
+        }
     if (active) {
       float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -326,7 +323,6 @@ int taco_launch_enc_lstm(taco_handle h, const float* gx, const int32_t* lens, in
     a.lens = lens; a.b = b;
     a.H = d.H_e; a.T = T; a.M = d.M; a.n_wg_dir = n_wg_dir;
     a.gran = h->enc_gran; a.ctl = h->enc_ctl;
-    a.timeout_ticks = 20000000ull;
     TACO_HIP(hipMemsetAsync(h->enc_gran, 0, h->enc_gran_count * sizeof(taco_granule), s));
     hipLaunchKernelGGL(taco_enc_lstm_kernel, dim3(2 * n_wg_dir), dim3(1024), 0, s, a);
     TACO_HIP(hipGetLastError());

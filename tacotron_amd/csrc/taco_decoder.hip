@@ -74,7 +74,8 @@ constexpr int L_RED = L_GATES + 16;                            // block-reductio
 constexpr int L_CELLS = L_RED + 32;                            // LSTM cell states [4 + 4]
 constexpr int L_BIAS = L_CELLS + 8;                            // b_ih + b_hh of my rows [16 + 16]
 constexpr int L_PROJB = L_BIAS + 32;                           // bias of my projection row [4]
-constexpr int L_TOTAL = L_PROJB + 4;
+constexpr int L_KEEP = L_PROJB + 4;                            // prenet keep bytes [2 frame parities][2 layers][256 B]
+constexpr int L_TOTAL = L_KEEP + 2 * 2 * 64;
 static_assert(L_TOTAL * 4 + 512 <= 160 * 1024, "decoder LDS carve exceeds a CU's 160 KiB");
 
 struct DecArgs {
@@ -169,34 +170,46 @@ __device__ __forceinline__ float lstm_cell_lanes(const float* gates_lds, const f
   return hv;
 }
 
+// STD = true fixes the extents of the usual checkpoint geometry (prenet 256, both LSTMs 1024, attention
+// 128 / 32 filters / kernel 31, 80 mel channels, 256 workgroups) at compile time: fewer live scalars and
+// no bounds arithmetic in the frame loop.  STD = false takes every extent from the arguments.
+template <bool STD>
 __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const DecArgs a) {
+  const int P = STD ? 256 : a.P;
+  const int Ra = STD ? 1024 : a.Ra;
+  const int Rd = STD ? 1024 : a.Rd;
+  const int A = STD ? 128 : a.A;
+  const int F = STD ? 32 : a.F;
+  const int K = STD ? 31 : a.K;
+  const int NMEL = STD ? 80 : a.n_mel;
+  const int M = a.M;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int j = blockIdx.x;
-  const int n_wg = a.n_wg;
+  const int n_wg = STD ? 256 : a.n_wg;
   const int len = a.lens ? min(a.lens[a.b], a.T_in) : a.T_in;
 
   for (int i = tid; i < L_TOTAL; i += NT) lds[i] = 0.0f;
   __syncthreads();
 
   // ---------------- one-time loads: this workgroup's slices of the model and of the utterance ----
-  const int Ua = (a.Ra + n_wg - 1) / n_wg;          // hidden units per workgroup (<= 4)
-  const int Ud = (a.Rd + n_wg - 1) / n_wg;
+  const int Ua = (Ra + n_wg - 1) / n_wg;          // hidden units per workgroup (<= 4)
+  const int Ud = (Rd + n_wg - 1) / n_wg;
   const int unit = wave >> 1, gate0 = (wave & 1) * 2;   // this wave's rows: gates gate0, gate0 + 1 of `unit`
   const int gu_a = j * Ua + unit, gu_d = j * Ud + unit;
-  const bool act_a = unit < Ua && gu_a < a.Ra;       // wave-uniform
-  const bool act_d = unit < Ud && gu_d < a.Rd;
+  const bool act_a = unit < Ua && gu_a < Ra;       // wave-uniform
+  const bool act_d = unit < Ud && gu_d < Rd;
 
   float wa[2][CH_A][4], wa_tail[2];
   float wd[2][CH_D][4], wd_tail[2];
   {
-    const int n_ih_a = a.P + a.M, n_ih_d = a.Ra + a.M;
+    const int n_ih_a = P + M, n_ih_d = Ra + M;
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-      const int ra = (gate0 + r) * a.Ra + gu_a;
-      const int rd = (gate0 + r) * a.Rd + gu_d;
+      const int ra = (gate0 + r) * Ra + gu_a;
+      const int rd = (gate0 + r) * Rd + gu_d;
 #pragma unroll
       for (int c = 0; c < CH_A; ++c) {
 #pragma unroll
@@ -205,13 +218,13 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
           if (act_a) {
             if (c < TACO_NP) {
               const int col = c * TACO_CHUNK + lane * 4 + e;
-              if (col < a.P) v = a.att_w_ih[(size_t)ra * n_ih_a + col];
+              if (col < P) v = a.att_w_ih[(size_t)ra * n_ih_a + col];
             } else if (c < TACO_NP + NMF) {
               const int col = (c - TACO_NP) * TACO_CHUNK + lane * 4 + e;
-              if (col < a.M) v = a.att_w_ih[(size_t)ra * n_ih_a + a.P + col];
+              if (col < M) v = a.att_w_ih[(size_t)ra * n_ih_a + P + col];
             } else {
               const int col = (c - TACO_NP - NMF) * TACO_CHUNK + lane * 4 + e;
-              if (col < a.Ra) v = a.att_w_hh[(size_t)ra * a.Ra + col];
+              if (col < Ra) v = a.att_w_hh[(size_t)ra * Ra + col];
             }
           }
           wa[r][c][e] = v;
@@ -226,65 +239,65 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
           if (act_d) {
             if (c < TACO_NA) {
               const int col = c * TACO_CHUNK + lane * 4 + e;
-              if (col < a.Ra) v = a.dec_w_ih[(size_t)rd * n_ih_d + col];
+              if (col < Ra) v = a.dec_w_ih[(size_t)rd * n_ih_d + col];
             } else if (c < TACO_NA + NMF) {
               const int col = (c - TACO_NA) * TACO_CHUNK + lane * 4 + e;
-              if (col < a.M) v = a.dec_w_ih[(size_t)rd * n_ih_d + a.Ra + col];
+              if (col < M) v = a.dec_w_ih[(size_t)rd * n_ih_d + Ra + col];
             } else {
               const int col = (c - TACO_NA - NMF) * TACO_CHUNK + lane * 4 + e;
-              if (col < a.Rd) v = a.dec_w_hh[(size_t)rd * a.Rd + col];
+              if (col < Rd) v = a.dec_w_hh[(size_t)rd * Rd + col];
             }
           }
           wd[r][c][e] = v;
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      wa_tail[r] = (act_a && CTX_TAIL0 + lane < a.M) ? a.att_w_ih[(size_t)ra * n_ih_a + a.P + CTX_TAIL0 + lane] : 0.0f;
-      wd_tail[r] = (act_d && CTX_TAIL0 + lane < a.M) ? a.dec_w_ih[(size_t)rd * n_ih_d + a.Ra + CTX_TAIL0 + lane] : 0.0f;
+      wa_tail[r] = (act_a && CTX_TAIL0 + lane < M) ? a.att_w_ih[(size_t)ra * n_ih_a + P + CTX_TAIL0 + lane] : 0.0f;
+      wd_tail[r] = (act_d && CTX_TAIL0 + lane < M) ? a.dec_w_ih[(size_t)rd * n_ih_d + Ra + CTX_TAIL0 + lane] : 0.0f;
       if (act_a && lane == 0) lds[L_BIAS + wave * 2 + r] = a.att_b_ih[ra] + a.att_b_hh[ra];
       if (act_d && lane == 0) lds[L_BIAS + 16 + wave * 2 + r] = a.dec_b_ih[rd] + a.dec_b_hh[rd];
     }
   }
 
-  const bool own_prenet = j < a.P;
-  const bool own_q = j < a.A;
+  const bool own_prenet = j < P;
+  const bool own_q = j < A;
   const int proj_row = j - a.proj_off;
-  const bool own_proj = proj_row >= 0 && proj_row <= a.n_mel;   // row n_mel is the stop-token row
-  const int n_hc = a.Rd + a.M;
-  for (int k = tid; k < a.P * a.n_mel; k += NT) {        // every workgroup keeps all of layer 1
-    const int r = k / a.n_mel, c = k % a.n_mel;
+  const bool own_proj = proj_row >= 0 && proj_row <= NMEL;   // row n_mel is the stop-token row
+  const int n_hc = Rd + M;
+  _Pragma("unroll 1") for (int k = tid; k < P * NMEL; k += NT) {        // every workgroup keeps all of layer 1
+    const int r = k / NMEL, c = k % NMEL;
     lds[L_W1T + c * (TACO_NP * TACO_CHUNK) + r] = a.prenet_w1[k];
   }
   if (own_prenet)
-    for (int k = tid; k < a.P; k += NT) lds[L_W2ROW + k] = a.prenet_w2[(size_t)j * a.P + k];
+    _Pragma("unroll 1") for (int k = tid; k < P; k += NT) lds[L_W2ROW + k] = a.prenet_w2[(size_t)j * P + k];
   if (own_q)
-    for (int k = tid; k < a.Ra; k += NT) lds[L_QROW + k] = a.query_w[(size_t)j * a.Ra + k];
+    _Pragma("unroll 1") for (int k = tid; k < Ra; k += NT) lds[L_QROW + k] = a.query_w[(size_t)j * Ra + k];
   if (own_proj) {
-    const float* src = proj_row < a.n_mel ? a.proj_w + (size_t)proj_row * n_hc : a.gate_w;
-    for (int k = tid; k < a.Rd; k += NT) lds[L_PROJROW + k] = src[k];
-    for (int k = tid; k < a.M; k += NT) lds[L_PROJROW + TACO_ND * TACO_CHUNK + k] = src[a.Rd + k];
-    if (tid == 0) lds[L_PROJB] = proj_row < a.n_mel ? a.proj_b[proj_row] : a.gate_b[0];
+    const float* src = proj_row < NMEL ? a.proj_w + (size_t)proj_row * n_hc : a.gate_w;
+    _Pragma("unroll 1") for (int k = tid; k < Rd; k += NT) lds[L_PROJROW + k] = src[k];
+    _Pragma("unroll 1") for (int k = tid; k < M; k += NT) lds[L_PROJROW + TACO_ND * TACO_CHUNK + k] = src[Rd + k];
+    if (tid == 0) lds[L_PROJB] = proj_row < NMEL ? a.proj_b[proj_row] : a.gate_b[0];
   }
-  for (int k = tid; k < a.F * 2 * a.K; k += NT) lds[L_LOCCONV + k] = a.loc_conv_w[k];
-  for (int k = tid; k < a.A * a.F; k += NT) {
-    const int aa = k / a.F, f = k % a.F;
+  _Pragma("unroll 1") for (int k = tid; k < F * 2 * K; k += NT) lds[L_LOCCONV + k] = a.loc_conv_w[k];
+  _Pragma("unroll 1") for (int k = tid; k < A * F; k += NT) {
+    const int aa = k / F, f = k % F;
     lds[L_LOCDT + f * TACO_MAX_A + aa] = a.loc_dense_w[k];
   }
-  for (int k = tid; k < a.A; k += NT) lds[L_V + k] = a.v_w[k];
+  _Pragma("unroll 1") for (int k = tid; k < A; k += NT) lds[L_V + k] = a.v_w[k];
   // per-utterance: processed-memory rows of my positions, memory columns of my context outputs
   for (int slot = 0; slot < TACO_E_SLOTS; ++slot) {
-    const int s = j + slot * n_wg;
+    const int s = (n_wg - 1 - j) + slot * n_wg;
     if (s < len)
-      for (int k = tid; k < a.A; k += NT) {
-        const float v = a.pm[(size_t)s * a.A + k];
+      _Pragma("unroll 1") for (int k = tid; k < A; k += NT) {
+        const float v = a.pm[(size_t)s * A + k];
         lds[L_PMROW + slot * TACO_MAX_A + k] = v;
         lds[L_U + slot * TACO_MAX_A + k] = v;     // location term is zero before the first frame
       }
   }
   for (int slot = 0; slot < TACO_C_SLOTS; ++slot) {
     const int m = j + slot * n_wg;
-    if (m < a.M)
-      for (int s = tid; s < len; s += NT) lds[L_MEMCOL + slot * TACO_MAX_TIN + s] = a.memory[(size_t)s * a.M + m];
+    if (m < M)
+      _Pragma("unroll 1") for (int s = tid; s < len; s += NT) lds[L_MEMCOL + slot * TACO_MAX_TIN + s] = a.memory[(size_t)s * M + m];
   }
   __syncthreads();
 
@@ -293,23 +306,32 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
   wctx.failed = 0;
 
   const bool forced = a.forced_mel != nullptr;
-  const int pad = (a.K - 1) / 2;
+  const int pad = (K - 1) / 2;
   int stopped = 0;
   int t = 0;
+  // attention-LSTM partial sums over [previous context | previous hidden]: computed at the end of
+  // each frame for the next one, in the shadow of the frame-output hand-off (zero before frame 0)
+  float acc_a[2] = {0.0f, 0.0f};
+  // Prenet keep bytes travel global -> LDS by LDS-DMA one frame ahead (no registers held across the
+  // frame); frame 0's are loaded here.
+  unsigned char* keep_lds = reinterpret_cast<unsigned char*>(lds + L_KEEP);
+  for (int k = tid; k < 2 * P; k += NT) keep_lds[(k / P) * 256 + (k % P)] = a.masks[k];
+  __syncthreads();
   for (;; ++t) {
     // ============ frame boundary: previous frame's output + every workgroup's heartbeat ============
     if (t > 0) {
       const taco_granule* gp = a.gran + (size_t)((t - 1) & 1) * a.lay.per_parity;
       const unsigned ep_prev = (unsigned)t;
-      if (tid <= a.n_mel) {
+      if (tid <= NMEL) {
         const float v = taco_wait_one(gp + a.lay.mel + (j % TACO_REP_SMALL) * a.lay.mel_cap, tid, ep_prev, wctx, 0x100u);
-        if (!forced || tid == a.n_mel) lds[L_MELIN + tid] = v;
+        if (!forced || tid == NMEL) lds[L_MELIN + tid] = v;
       } else if (tid >= 128 && tid < 128 + n_wg) {
         (void)taco_wait_one(gp + a.lay.beat + (j % TACO_REP_SMALL) * a.lay.beat_cap, tid - 128, ep_prev, wctx, 0x200u);
       }
-      if (forced && tid < a.n_mel) lds[L_MELIN + tid] = a.forced_mel[(size_t)tid * a.T_cap + (t - 1)];
+      if (forced && tid < NMEL) lds[L_MELIN + tid] = a.forced_mel[(size_t)tid * a.T_cap + (t - 1)];
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the keep-byte DMA issued last frame has landed
       if (__syncthreads_or(wctx.failed)) break;
-      if (!forced && taco_sigmoid(lds[L_MELIN + a.n_mel]) > a.thr) { stopped = 1; break; }
+      if (!forced && taco_sigmoid(lds[L_MELIN + NMEL]) > a.thr) { stopped = 1; break; }
     }
     if (t == a.max_steps) break;
       TACO_STAMP(0);
@@ -318,9 +340,16 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
     taco_granule* g = a.gran + (size_t)(t & 1) * a.lay.per_parity;
     // keep-bits of the two prenet dropouts: layer 1 for the row this thread finishes, layer 2 for row j
     constexpr int PW = TACO_NP * TACO_CHUNK;
-    unsigned keep1 = 0, keep2 = 0;
-    if (tid < a.P) keep1 = a.masks[((size_t)t * 2 + 0) * a.P + tid];
-    if (own_prenet) keep2 = a.masks[((size_t)t * 2 + 1) * a.P + j];
+    const unsigned char* keep_now = keep_lds + (t & 1) * 512;
+    if (wave == NT / 64 - 1 && t + 1 < a.max_steps && lane * 4 < P) {
+      // next frame's keep bytes, fetched a frame ahead (a first-touch line comes from HBM)
+      const unsigned char* src = a.masks + (size_t)(t + 1) * 2 * P + lane * 4;
+      float* dst = lds + L_KEEP + ((t + 1) & 1) * 128;
+      typedef const __attribute__((address_space(1))) void* gptr_t;
+      typedef __attribute__((address_space(3))) void* lptr_t;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 4, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(src + P), (lptr_t)(dst + 64), 4, 0, 0);
+    }
 
     // ============ S1: prenet layer 1, ALL rows, replicated in every workgroup (20 k MACs buy one hop) ====
     // thread = (4 adjacent rows, one of 8 slices of the input columns); rows beyond P, columns beyond
@@ -340,22 +369,13 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
       }
       *reinterpret_cast<float4*>(lds + L_P1HALF + kp * PW + rq * 4) = acc;
     }
-    // meanwhile: attention-LSTM partial sums over [previous context | previous hidden]
-    float acc_a[2] = {0.0f, 0.0f};
-    if (act_a) {
-      dot_chunks<NMF>(wa[0] + TACO_NP, wa[1] + TACO_NP, lds + L_XCTX, lane, acc_a);
-      const float xt = lds[L_XCTX + CTX_TAIL0 + lane];
-      acc_a[0] = fmaf(wa_tail[0], xt, acc_a[0]);
-      acc_a[1] = fmaf(wa_tail[1], xt, acc_a[1]);
-      dot_chunks<TACO_NA>(wa[0] + TACO_NP + NMF, wa[1] + TACO_NP + NMF, lds + L_XAH, lane, acc_a);
-    }
     taco_lds_barrier();
     if (tid < PW) {
       float v = 0.0f;
 #pragma unroll
       for (int i = 0; i < P1_KPARTS; ++i) v += lds[L_P1HALF + i * PW + tid];
       v = v > 0.0f ? v : 0.0f;
-      lds[L_P1 + tid] = keep1 ? v * 2.0f : 0.0f;
+      lds[L_P1 + tid] = keep_now[tid] ? v * 2.0f : 0.0f;
     }
     taco_lds_barrier();
     TACO_STAMP(1);
@@ -365,12 +385,12 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
     if (own_prenet && wave == 0) {
       float v = taco_wave_sum(row_partial<TACO_NP>(lds + L_W2ROW, lds + L_P1, lane));
       v = v > 0.0f ? v : 0.0f;
-      v = keep2 ? v * 2.0f : 0.0f;
+      v = keep_now[256 + j] ? v * 2.0f : 0.0f;
       if (lane == 0) taco_publish_rep<TACO_REP_SMALL>(g + a.lay.p, a.lay.p_cap, j, ep, v);
     }
 
     // ============ S3: attention LSTM ============
-    taco_gather<NT>(g + a.lay.p + (j % TACO_REP_SMALL) * a.lay.p_cap, a.P, ep, lds + L_XP, wctx, 0x400u);
+    taco_gather<NT>(g + a.lay.p + (j % TACO_REP_SMALL) * a.lay.p_cap, P, ep, lds + L_XP, wctx, 0x400u);
     TACO_STAMP(3);
     if (act_a) {
       dot_chunks<TACO_NP>(wa[0], wa[1], lds + L_XP, lane, acc_a);
@@ -385,7 +405,7 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
     if (wave == 0) {
       const float hv = lstm_cell_lanes(lds + L_GATES, lds + L_BIAS, lds + L_CELLS, lane);
       const int u = lane >> 2;
-      if ((lane & 3) == 0 && u < Ua && j * Ua + u < a.Ra) taco_publish_rep<TACO_REP_BIG>(g + a.lay.ah, a.lay.ah_cap, j * Ua + u, ep, hv);
+      if ((lane & 3) == 0 && u < Ua && j * Ua + u < Ra) taco_publish_rep<TACO_REP_BIG>(g + a.lay.ah, a.lay.ah_cap, j * Ua + u, ep, hv);
     }
     // meanwhile: decoder-LSTM partial over the previous decoder hidden state
     float acc_d[2] = {0.0f, 0.0f};
@@ -393,7 +413,7 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
 
     // ============ S4: query projection, row j ============
     TACO_STAMP(4);
-    taco_gather<NT>(g + a.lay.ah + (j % TACO_REP_BIG) * a.lay.ah_cap, a.Ra, ep, lds + L_XAH, wctx, 0x500u);
+    taco_gather<NT>(g + a.lay.ah + (j % TACO_REP_BIG) * a.lay.ah_cap, Ra, ep, lds + L_XAH, wctx, 0x500u);
     TACO_STAMP(5);
     if (own_q && wave == 0) {
       const float v = taco_wave_sum(row_partial<TACO_NA>(lds + L_QROW, lds + L_XAH, lane));
@@ -402,13 +422,13 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
     if (act_d) dot_chunks<TACO_NA>(wd[0], wd[1], lds + L_XAH, lane, acc_d);
 
     // ============ S5: energies of my positions ============
-    taco_gather<NT>(g + a.lay.q + (j % TACO_REP_SMALL) * a.lay.q_cap, a.A, ep, lds + L_Q, wctx, 0x600u);
+    taco_gather<NT>(g + a.lay.q + (j % TACO_REP_SMALL) * a.lay.q_cap, A, ep, lds + L_Q, wctx, 0x600u);
     TACO_STAMP(6);
     if (wave < TACO_E_SLOTS) {
-      const int s = j + wave * n_wg;
+      const int s = (n_wg - 1 - j) + wave * n_wg;
       if (s < len) {
         float acc = 0.0f;
-        for (int aa = lane; aa < a.A; aa += 64)
+        for (int aa = lane; aa < A; aa += 64)
           acc = fmaf(lds[L_V + aa], taco_tanh(lds[L_Q + aa] + lds[L_U + wave * TACO_MAX_A + aa]), acc);
         acc = taco_wave_sum(acc);
         if (lane == 0) taco_publish_rep<TACO_REP_SMALL>(g + a.lay.e, a.lay.e_cap, s, ep, acc);
@@ -461,7 +481,7 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
     }
     if (wave < TACO_C_SLOTS) {
       const int m = j + wave * n_wg;
-      if (m < a.M) {
+      if (m < M) {
         float acc = 0.0f;
         for (int s = lane; s < len; s += 64)
           acc = fmaf(lds[L_AW + HALO + s], lds[L_MEMCOL + wave * TACO_MAX_TIN + s], acc);
@@ -472,42 +492,51 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
 
     // while the context travels: location features of my positions for the NEXT frame (they need
     // only this frame's weights and cumulative weights, which are final now)
-    if (tid < 256) {
-      const int f = tid >> 3, part = tid & 7;
+    {
+      // location conv: 16 lanes per filter (32 filters x 16 = all 512 threads), taps split 16 ways
+      const int f = tid >> 4, part = tid & 15;
       for (int slot = 0; slot < TACO_E_SLOTS; ++slot) {
-        const int s = j + slot * n_wg;
+        const int s = (n_wg - 1 - j) + slot * n_wg;
         if (s >= len) break;
         float acc = 0.0f;
-        if (f < a.F) {
-          for (int kk = part; kk < 2 * a.K; kk += 8) {
-            const int c = kk >= a.K ? 1 : 0;
-            const int k = kk - c * a.K;
+        if (f < F) {
+#pragma unroll 4
+          for (int kk = part; kk < 2 * K; kk += 16) {
+            const int c = kk >= K ? 1 : 0;
+            const int k = kk - c * K;
             const float x = lds[(c ? L_CUM : L_AW) + HALO + s + k - pad];
-            acc = fmaf(lds[L_LOCCONV + (f * 2 + c) * a.K + k], x, acc);
+            acc = fmaf(lds[L_LOCCONV + (f * 2 + c) * K + k], x, acc);
           }
         }
-        acc += __shfl_xor(acc, 4, 64);
-        acc += __shfl_xor(acc, 2, 64);
-        acc += __shfl_xor(acc, 1, 64);
-        if (part == 0 && f < a.F) lds[L_CONVOUT + slot * TACO_MAX_F + f] = acc;
+        acc = taco_sum16(acc);
+        if (part == 0 && f < F) lds[L_CONVOUT + slot * TACO_MAX_F + f] = acc;
       }
     }
     taco_lds_barrier();
-    if (tid < TACO_E_SLOTS * TACO_MAX_A) {
-      const int slot = tid >> 7, aa = tid & 127;
-      const int s = j + slot * n_wg;
-      if (s < len && aa < a.A) {
+    {
+      // location dense + processed memory: 4 lanes per attention dimension (128 x 4 = 512 threads)
+      const int aa = tid >> 2, fq = tid & 3;
+      for (int slot = 0; slot < TACO_E_SLOTS; ++slot) {
+        const int s = (n_wg - 1 - j) + slot * n_wg;
+        if (s >= len) break;
         float loc = 0.0f;
-        for (int f = 0; f < a.F; ++f)
-          loc = fmaf(lds[L_LOCDT + f * TACO_MAX_A + aa], lds[L_CONVOUT + slot * TACO_MAX_F + f], loc);
-        lds[L_U + slot * TACO_MAX_A + aa] = loc + lds[L_PMROW + slot * TACO_MAX_A + aa];
+        if (aa < A) {
+#pragma unroll 4
+          for (int f = fq; f < F; f += 4)
+            loc = fmaf(lds[L_LOCDT + f * TACO_MAX_A + aa], lds[L_CONVOUT + slot * TACO_MAX_F + f], loc);
+        }
+        loc = taco_sum4(loc);
+        if (fq == 0 && aa < A) lds[L_U + slot * TACO_MAX_A + aa] = loc + lds[L_PMROW + slot * TACO_MAX_A + aa];
       }
     }
 
     // ============ S7: decoder LSTM ============
     TACO_STAMP(8);
-    taco_gather<NT>(g + a.lay.ctx + (j % TACO_REP_CTX) * a.lay.ctx_cap, a.M, ep, lds + L_XCTX, wctx, 0x800u);
+    taco_gather<NT>(g + a.lay.ctx + (j % TACO_REP_CTX) * a.lay.ctx_cap, M, ep, lds + L_XCTX, wctx, 0x800u);
     TACO_STAMP(9);
+    // heartbeat: every hand-off vector of frame t except the decoder hidden state and the frame
+    // output has been consumed by this workgroup
+    if (tid == NT - 64) taco_publish_rep<TACO_REP_SMALL>(g + a.lay.beat, a.lay.beat_cap, j, ep, 0.0f);
     if (act_d) {
       dot_chunks<NMF>(wd[0] + TACO_NA, wd[1] + TACO_NA, lds + L_XCTX, lane, acc_d);
       const float xt = lds[L_XCTX + CTX_TAIL0 + lane];
@@ -524,7 +553,7 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
     if (wave == 0) {
       const float hv = lstm_cell_lanes(lds + L_GATES, lds + L_BIAS + 16, lds + L_CELLS + 4, lane);
       const int u = lane >> 2;
-      if ((lane & 3) == 0 && u < Ud && j * Ud + u < a.Rd) taco_publish_rep<TACO_REP_BIG>(g + a.lay.dh, a.lay.dh_cap, j * Ud + u, ep, hv);
+      if ((lane & 3) == 0 && u < Ud && j * Ud + u < Rd) taco_publish_rep<TACO_REP_BIG>(g + a.lay.dh, a.lay.dh_cap, j * Ud + u, ep, hv);
     }
     // meanwhile: context half of my projection row
     float acc_p = 0.0f;
@@ -532,19 +561,26 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
 
     // ============ S8: mel / stop-token projection, row proj_row ============
     TACO_STAMP(10);
-    taco_gather<NT>(g + a.lay.dh + (j % TACO_REP_BIG) * a.lay.dh_cap, a.Rd, ep, lds + L_XDH, wctx, 0x900u);
+    taco_gather<NT>(g + a.lay.dh + (j % TACO_REP_BIG) * a.lay.dh_cap, Rd, ep, lds + L_XDH, wctx, 0x900u);
     TACO_STAMP(11);
-    // heartbeat: every hand-off vector of frame t except the frame output has been consumed here
-    // (published by a wave that does not poll at the frame boundary)
-    if (tid == NT - 64) taco_publish_rep<TACO_REP_SMALL>(g + a.lay.beat, a.lay.beat_cap, j, ep, 0.0f);
     if (own_proj && wave == 1) {
       acc_p += row_partial<TACO_ND>(lds + L_PROJROW, lds + L_XDH, lane);
       const float v = taco_wave_sum(acc_p) + lds[L_PROJB];
       if (lane == 0) {
         taco_publish_rep<TACO_REP_SMALL>(g + a.lay.mel, a.lay.mel_cap, proj_row, ep, v);
-        if (proj_row < a.n_mel) a.mel[(size_t)proj_row * a.T_cap + t] = v;
+        if (proj_row < NMEL) a.mel[(size_t)proj_row * a.T_cap + t] = v;
         else a.gate[t] = v;
       }
+    }
+    // while the frame output travels: next frame's attention-LSTM partial sums
+    acc_a[0] = 0.0f;
+    acc_a[1] = 0.0f;
+    if (act_a) {
+      dot_chunks<NMF>(wa[0] + TACO_NP, wa[1] + TACO_NP, lds + L_XCTX, lane, acc_a);
+      const float xt = lds[L_XCTX + CTX_TAIL0 + lane];
+      acc_a[0] = fmaf(wa_tail[0], xt, acc_a[0]);
+      acc_a[1] = fmaf(wa_tail[1], xt, acc_a[1]);
+      dot_chunks<TACO_NA>(wa[0] + TACO_NP + NMF, wa[1] + TACO_NP + NMF, lds + L_XAH, lane, acc_a);
     }
   }
 
@@ -584,6 +620,7 @@ size_t taco_decoder_granules(int n_wg) {
 }
 
 int taco_decoder_check_dims(const taco_dims& d, int n_wg) {
+  if (d.P % 4 != 0) TACO_FAIL(TACO_EINVAL, "prenet_dim %d must be a multiple of 4", d.P);
   if (d.P > TACO_NP * TACO_CHUNK || d.P > n_wg) TACO_FAIL(TACO_EINVAL, "prenet_dim %d exceeds the decoder kernel's capacity %d", d.P, TACO_NP * TACO_CHUNK < n_wg ? TACO_NP * TACO_CHUNK : n_wg);
   if (d.M > TACO_M_LSTM_MAX || d.M > TACO_C_SLOTS * n_wg) TACO_FAIL(TACO_EINVAL, "memory width %d exceeds the decoder kernel's capacity %d", d.M, TACO_M_LSTM_MAX);
   if (d.R_a > TACO_NA * TACO_CHUNK || d.R_a > TACO_UNITS_PER_WG * n_wg) TACO_FAIL(TACO_EINVAL, "attention_rnn_dim %d exceeds the decoder kernel's capacity", d.R_a);
@@ -607,7 +644,7 @@ int taco_launch_decoder(taco_handle h, const float* memory, const float* pm, int
   DecArgs a;
   a.P = d.P; a.M = d.M; a.Ra = d.R_a; a.Rd = d.R_d; a.A = d.A; a.F = d.F; a.K = d.K; a.n_mel = d.n_mel;
   a.T_in = T_in; a.lens = lens; a.b = b; a.n_wg = n_wg;
-  a.proj_off = (d.A + d.n_mel + 1 <= n_wg) ? d.A : 0;
+  a.proj_off = 0;   // projection rows on workgroups 0..n_mel; attention positions count down from the last workgroup
   const taco_weights& w = h->w;
   a.prenet_w1 = w.prenet_w1; a.prenet_w2 = w.prenet_w2;
   a.att_w_ih = w.att_w_ih; a.att_w_hh = w.att_w_hh; a.att_b_ih = w.att_b_ih; a.att_b_hh = w.att_b_hh;
@@ -633,7 +670,10 @@ int taco_launch_decoder(taco_handle h, const float* memory, const float* pm, int
   a.stamps = stamps_dev;
 #endif
   TACO_HIP(hipEventRecord(h->ev_start, s));
-  hipLaunchKernelGGL(taco_decoder_kernel, dim3(n_wg), dim3(NT), taco_decoder_lds_bytes(), s, a);
+  const bool std_geom = d.P == 256 && d.R_a == 1024 && d.R_d == 1024 && d.A == 128 && d.F == 32 && d.K == 31 &&
+                        d.n_mel == 80 && n_wg == 256;
+  if (std_geom) hipLaunchKernelGGL(taco_decoder_kernel<true>, dim3(n_wg), dim3(NT), taco_decoder_lds_bytes(), s, a);
+  else hipLaunchKernelGGL(taco_decoder_kernel<false>, dim3(n_wg), dim3(NT), taco_decoder_lds_bytes(), s, a);
   TACO_HIP(hipGetLastError());
   TACO_HIP(hipEventRecord(h->ev_stop, s));
   h->timing_valid = 1;
@@ -681,10 +721,14 @@ void taco_decoder_fill_layout(taco_dec_layout* lay, int n_wg) { fill_layout(*lay
 
 int taco_decoder_prepare(taco_handle h) {
   // the kernel needs more than the default 64 KiB of dynamic LDS
-  TACO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(taco_decoder_kernel),
+  TACO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(taco_decoder_kernel<true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)taco_decoder_lds_bytes()));
+  TACO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(taco_decoder_kernel<false>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)taco_decoder_lds_bytes()));
   int per_cu = 0;
-  TACO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, taco_decoder_kernel, NT, taco_decoder_lds_bytes()));
+  TACO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, taco_decoder_kernel<true>, NT, taco_decoder_lds_bytes()));
+  if (per_cu < 1) TACO_FAIL(TACO_EINVAL, "decoder kernel does not fit on a CU (occupancy query returned %d)", per_cu);
+  TACO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, taco_decoder_kernel<false>, NT, taco_decoder_lds_bytes()));
   if (per_cu < 1) TACO_FAIL(TACO_EINVAL, "decoder kernel does not fit on a CU (occupancy query returned %d)", per_cu);
   (void)h;
   return TACO_OK;

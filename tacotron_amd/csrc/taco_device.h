@@ -51,6 +51,27 @@ __device__ __forceinline__ float taco_wave_sum(float v) {
   v += taco_dpp_rot<0x121>(v);
   return (taco_lane_value(v, 0) + taco_lane_value(v, 16)) + (taco_lane_value(v, 32) + taco_lane_value(v, 48));
 }
+// Sum over each aligned group of 8 lanes (quad swaps, then the half-row mirror); every lane of a
+// group receives the group's total.
+__device__ __forceinline__ float taco_sum8(float v) {
+  v += taco_dpp_rot<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += taco_dpp_rot<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += taco_dpp_rot<0x141>(v);   // row_half_mirror
+  return v;
+}
+// Sum over each row of 16 lanes / each quad; every lane of the group receives the total.
+__device__ __forceinline__ float taco_sum16(float v) {
+  v += taco_dpp_rot<0x128>(v);
+  v += taco_dpp_rot<0x124>(v);
+  v += taco_dpp_rot<0x122>(v);
+  v += taco_dpp_rot<0x121>(v);
+  return v;
+}
+__device__ __forceinline__ float taco_sum4(float v) {
+  v += taco_dpp_rot<0xB1>(v);
+  v += taco_dpp_rot<0x4E>(v);
+  return v;
+}
 __device__ __forceinline__ float taco_wave_max(float v) {
   v = fmaxf(v, taco_dpp_rot<0x128>(v));
   v = fmaxf(v, taco_dpp_rot<0x124>(v));
@@ -68,6 +89,21 @@ __device__ __forceinline__ float taco_wave_sum(float v) {
 __device__ __forceinline__ float taco_wave_max(float v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+  return v;
+}
+__device__ __forceinline__ float taco_sum8(float v) {
+  v += __shfl_xor(v, 4, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 1, 64);
+  return v;
+}
+__device__ __forceinline__ float taco_sum16(float v) {
+  v = taco_sum8(v);
+  return v + __shfl_xor(v, 8, 64);
+}
+__device__ __forceinline__ float taco_sum4(float v) {
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 1, 64);
   return v;
 }
 #endif

@@ -63,7 +63,7 @@ def cpu_baseline(ckpt, sym, st, spk, target_s):
   t0 = time.perf_counter()
   om.decode(mem, pm, None, masks, probe, gate_threshold=never, want_align=True)
   per_frame = (time.perf_counter() - t0) / probe
-  frames = int(min(6000, max(200, target_s / max(per_frame, 1e-6))))
+  frames = int(min(60000, max(200, target_s / max(per_frame, 1e-6))))
   masks = prenet_keep_masks(1111, frames, om.dims.P).numpy()
   t0 = time.perf_counter()
   mem, pm = om.encode([sym, st], spk, None)
@@ -157,6 +157,14 @@ def main():
   achieved = bytes_per_frame * frames / dec_s / 1e9
   hop = hp.hop_length
   audio_s = (frames - 1) * hop / 22050.0
+  # HBM bytes of the decoder kernel from the committed PMC profile (rocprofv3 cannot run inside this
+  # process); per frame, scaled to this launch's frame count
+  traffic = None
+  try:
+    with open(os.path.join(ROOT, "profiles", "r1c_pmc_traffic.json")) as f:
+      traffic = int(json.load(f)["hbm_bytes_per_frame"] * frames)
+  except (OSError, KeyError, ValueError):
+    traffic = None
   out = {
     "metric": "mel frames/sec", "value": round(value, 1), "unit": "mel frames/s", "n_gpus": world,
     "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -167,7 +175,7 @@ def main():
     "real_time_factor": round(world * args.steps * audio_s / elapsed, 1),
     "decoder_us_per_frame": round(dec_s / frames * 1e6, 3),
     "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                  "kernel": "taco_decoder_kernel", "bytes_per_frame": int(bytes_per_frame),
                  "kernel_ms_per_launch": round(dec_s * 1e3, 4)},
   }

@@ -112,6 +112,10 @@ class Synthesizer:
   def get_sampling_rate(self) -> int:
     return self.hparams.sampling_rate
 
+  def _sync(self) -> None:
+    if self.device.type == "cuda":
+      torch.cuda.synchronize(self.device)
+
   # ---- host logic: symbols -> ids, dropping positions no mapping knows ---------------------------
   def _prepare(self, symbols: Sequence[str], speaker: Optional[str]) -> _Prepared:
     logger = logging.getLogger(__name__)
@@ -173,12 +177,12 @@ class Synthesizer:
     if self.hparams.use_speaker_embedding:
       speaker_tensor = torch.full(tuple(symbol_tensor.shape), prep.speaker_id, dtype=torch.int64, device=self.device)
 
-    torch.cuda.synchronize(self.device)
+    self._sync()
     start = time.perf_counter()
     mel, mel_post, gate, align, reached = self.model.inference(
       symbols=symbol_tensor, stresses=tensor(prep.ids["stresses"]), tones=tensor(prep.ids["tones"]),
       durations=tensor(prep.ids["durations"]), speakers=speaker_tensor, max_decoder_steps=max_decoder_steps)
-    torch.cuda.synchronize(self.device)
+    self._sync()
     seconds = time.perf_counter() - start
 
     def to_np(t):
@@ -215,12 +219,12 @@ class Synthesizer:
     if self.hparams.use_speaker_embedding:
       speakers = torch.full((len(preps), T), preps[0].speaker_id, dtype=torch.int64, device=self.device)
     lens_t = torch.tensor(lens, dtype=torch.int32, device=self.device)
-    torch.cuda.synchronize(self.device)
+    self._sync()
     start = time.perf_counter()
     mel, post, gate, align, n_frames, reached = self.model.inference_batch(
       padded("symbols"), padded("stresses"), padded("tones"), padded("durations"), speakers, lens_t,
       max_decoder_steps, want_align=include_stats)
-    torch.cuda.synchronize(self.device)
+    self._sync()
     seconds = (time.perf_counter() - start) / len(preps)
     n_frames = n_frames.cpu().tolist()
     reached = reached.cpu().tolist()

@@ -248,3 +248,30 @@ def test_error_reporting():
   bad[0, 0] = 10 ** 6
   with pytest.raises(IndexError):
     gm.encode([dev(bad)] + [dev(c) for c in chans(ids)[1:]], dev(ids["speakers"]), None)
+
+
+def test_synthesize_command_on_gpu_matches_oracle_backed_run(tmp_path):
+  """The synthesize command through the HIP library writes the files the same command writes with
+  the CPU oracle as its model: same names, same frame counts, frames within the free-running bound."""
+  import os
+  from conftest import GOLDEN
+  from oracle_shim import oracle_synthesizer
+  from tacotron_amd import cli
+  ckpt = os.path.join(GOLDEN, "tiny_checkpoint.pt")
+  r = np.random.RandomState(9)
+  lines = ["|".join(f"s{r.randint(1, 31)}" for _ in range(r.randint(2, 14))) for _ in range(7)]
+  lines.insert(3, "")
+  text = tmp_path / "in.txt"
+  text.write_text("\n".join(lines), encoding="UTF-8")
+  common = ["synthesize", ckpt, str(text), "--sep", "|", "--custom-seed", "5", "--max-decoder-steps", "18"]
+  ns = cli.build_parser().parse_args(common + ["-out", str(tmp_path / "oracle")])
+  assert ns.handler(ns, synthesizer_factory=oracle_synthesizer)
+  for sub, extra in (("gpu", []), ("gpu_batched", ["--batch-size", "4"])):
+    ns = cli.build_parser().parse_args(common + ["-out", str(tmp_path / sub), "--device", "cuda:0"] + extra)
+    assert ns.handler(ns)
+    names = sorted(p.name for p in (tmp_path / "oracle").iterdir())
+    assert len(names) == 7 and names == sorted(p.name for p in (tmp_path / sub).iterdir())
+    for n in names:
+      want, got = np.load(tmp_path / "oracle" / n), np.load(tmp_path / sub / n)
+      assert got.shape == want.shape and got.dtype == np.float32
+      np.testing.assert_allclose(got, want, atol=FREE_TOL, rtol=0)

@@ -1,0 +1,81 @@
+"""The N > 1 path: lines partitioned over one process per GPU, host-side gather of the records.
+Run here with world_size 2 over gloo and the CPU oracle in place of the GPU model."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+from tacotron_amd import sharding
+
+TINY_CKPT = os.path.join(GOLDEN, "tiny_checkpoint.pt")
+WORKER = os.path.join(ROOT, "tests", "shard_worker.py")
+
+
+def test_lpt_partition_covers_balances_and_is_deterministic():
+  r = np.random.RandomState(0)
+  costs = r.randint(20, 201, size=1000).astype(float)
+  for n in (1, 2, 4, 8):
+    shards = sharding.lpt_partition(costs, n)
+    assert sorted(i for s in shards for i in s) == list(range(1000))
+    loads = sharding.shard_loads(costs, shards)
+    assert max(loads) - min(loads) <= costs.max()              # LPT bound for equal-speed shards
+    assert shards == sharding.lpt_partition(list(costs), n)
+    for s in shards:                                           # descending cost inside a shard
+      assert all(costs[a] >= costs[b] for a, b in zip(s, s[1:]))
+  assert sharding.lpt_partition([], 3) == [[], [], []]
+  assert sharding.lpt_partition([5.0], 2) == [[0], []]
+  with pytest.raises(ValueError):
+    sharding.lpt_partition([1.0], 0)
+  assert sharding.batches([4, 2, 9, 1, 7], 2) == [[4, 2], [9, 1], [7]]
+
+
+def test_run_sharded_single_process_orders_records():
+  out = sharding.run_sharded(5, [3, 1, 4, 1, 5], lambda idx: {i: f"r{i}" for i in idx})
+  assert out == ["r0", "r1", "r2", "r3", "r4"]
+  with pytest.raises(RuntimeError):
+    sharding.run_sharded(3, [1, 1, 1], lambda idx: {})         # a record is missing
+
+
+def _free_port():
+  with socket.socket() as s:
+    s.bind(("127.0.0.1", 0))
+    return s.getsockname()[1]
+
+
+def _launch(n, args, timeout=300):
+  env = dict(os.environ, OMP_NUM_THREADS="1", PYTHONPATH=ROOT)
+  cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+         "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), WORKER] + args
+  return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_two_ranks_write_the_same_files_as_one(tmp_path):
+  r = np.random.RandomState(4)
+  lines = []
+  for i in range(11):
+    if i in (4, 8):
+      lines.append("")
+    lines.append("|".join(f"s{r.randint(1, 31)}" for _ in range(r.randint(2, 12))))
+  text = tmp_path / "in.txt"
+  text.write_text("\n".join(lines), encoding="UTF-8")
+  common = ["synthesize", TINY_CKPT, str(text), "--sep", "|", "--custom-seed", "5", "--max-decoder-steps", "14"]
+  one = _launch(1, common + ["-out", str(tmp_path / "one")])
+  assert one.returncode == 0, one.stdout + one.stderr
+  two = _launch(2, common + ["-out", str(tmp_path / "two"), "--batch-size", "2"])
+  assert two.returncode == 0, two.stdout + two.stderr
+  assert "rank 0/2 ok=True" in two.stdout and "rank 1/2 ok=True" in two.stdout
+  names = sorted(p.name for p in (tmp_path / "one").iterdir())
+  assert len(names) == 11 and names == sorted(p.name for p in (tmp_path / "two").iterdir())
+  for n in names:
+    np.testing.assert_array_equal(np.load(tmp_path / "one" / n), np.load(tmp_path / "two" / n))
+
+
+def test_a_failing_rank_is_reported_on_every_rank_without_a_hang():
+  res = _launch(2, ["fail"], timeout=120)
+  assert res.returncode == 0, res.stdout + res.stderr
+  assert "rank 0 raised RuntimeError: rank 1 failed" in res.stdout
+  assert "rank 1 raised ValueError: boom on rank 1" in res.stdout

@@ -152,7 +152,10 @@ extern "C" int taco_create(const taco_dims* dims, const taco_weights* weights, i
   size_t n_bn_post = 0;
   for (int l = 0; l < d.n_post; ++l) n_bn_post += 2 * (size_t)(((l == d.n_post - 1 ? d.n_mel : d.C_post) + 63) / 64 * 64);
   const size_t n_wcat = (size_t)8 * d.H_e * d.E, n_bsum = (size_t)8 * d.H_e;
-  h->pool_floats = plan.total + n_bn_enc + n_bn_post + (n_wcat + 63) / 64 * 64 + (n_bsum + 63) / 64 * 64;
+  h->ctx_rows = 4 * d.R_a + 4 * d.R_d + d.n_mel + 1;
+  const size_t n_ctxw = (size_t)h->ctx_rows * d.M;
+  h->pool_floats = plan.total + n_bn_enc + n_bn_post + (n_wcat + 63) / 64 * 64 + (n_bsum + 63) / 64 * 64 +
+                   (n_ctxw + 63) / 64 * 64;
   if (hipMalloc((void**)&h->pool, h->pool_floats * sizeof(float)) != hipSuccess) {
     delete h;
     TACO_FAIL(TACO_ENOMEM, "hipMalloc of %zu bytes for the weight pool failed", h->pool_floats * sizeof(float));
@@ -191,7 +194,21 @@ extern "C" int taco_create(const taco_dims* dims, const taco_weights* weights, i
     hipLaunchKernelGGL(taco_add_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, hw.enc_lstm_b_ih[dir],
                        hw.enc_lstm_b_hh[dir], h->lstm_bias_sum + (size_t)dir * n, n);
   }
+  h->ctx_w_cat = cur; cur += (n_ctxw + 63) / 64 * 64;
+  {
+    float* dst = h->ctx_w_cat;
+    rc = taco_launch_slice_cols(hw.att_w_ih, d.P + d.M, d.P, 4 * d.R_a, d.M, dst, 0);
+    dst += (size_t)4 * d.R_a * d.M;
+    if (rc == TACO_OK) rc = taco_launch_slice_cols(hw.dec_w_ih, d.R_a + d.M, d.R_a, 4 * d.R_d, d.M, dst, 0);
+    dst += (size_t)4 * d.R_d * d.M;
+    if (rc == TACO_OK) rc = taco_launch_slice_cols(hw.proj_w, d.R_d + d.M, d.R_d, d.n_mel, d.M, dst, 0);
+    dst += (size_t)d.n_mel * d.M;
+    if (rc == TACO_OK) rc = taco_launch_slice_cols(hw.gate_w, d.R_d + d.M, d.R_d, 1, d.M, dst, 0);
+    if (rc != TACO_OK) { taco_destroy(h); return rc; }
+  }
   TACO_CREATE_HIP(hipGetLastError());
+  TACO_CREATE_HIP(hipMalloc((void**)&h->ws_memT, sizeof(float) * (size_t)d.M * TACO_MAX_TIN));
+  TACO_CREATE_HIP(hipMalloc((void**)&h->ws_G, sizeof(float) * (size_t)h->ctx_rows * TACO_MAX_TIN));
 
   // ---- hand-off words, control blocks, events ----
   taco_decoder_fill_layout(&h->dec_lay, h->n_cu);
@@ -220,6 +237,8 @@ extern "C" int taco_destroy(taco_handle h) {
   for (int i = 0; i < 2; ++i)
     if (h->ws_act[i]) (void)hipFree(h->ws_act[i]);
   if (h->ws_gx) (void)hipFree(h->ws_gx);
+  if (h->ws_memT) (void)hipFree(h->ws_memT);
+  if (h->ws_G) (void)hipFree(h->ws_G);
   if (h->enc_gran) (void)hipFree(h->enc_gran);
   if (h->dec_gran) (void)hipFree(h->dec_gran);
   if (h->dec_ctl) (void)hipFree(h->dec_ctl);

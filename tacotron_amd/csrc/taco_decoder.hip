@@ -17,6 +17,11 @@
 //   * workgroups exchange activation vectors through 8-byte {epoch, fp32} granules written with
 //     agent-scope (write-through) stores and polled with agent-scope loads: the value is its own
 //     ready flag, so no grid barrier and no cache fence sits between the dependent steps;
+//   * the attention context never travels: ctx = sum_s w_s * memory_s enters the frame only through
+//     W * ctx (both LSTMs' input rows and the projection rows), and W * ctx = (W * memory^T) * w.
+//     G = W_ctx * memory^T is computed once per utterance (a GEMM before this launch); the kernel keeps
+//     its G rows where the context columns of the weight rows would sit (registers / LDS) and
+//     multiplies them with the attention weights every workgroup already has after its softmax;
 //   * everything that does not depend on the value being waited for (the recurrent halves of the
 //     LSTM dot products, location features) is computed before the wait.
 // Granule slots are double-buffered by frame parity and every workgroup publishes a per-frame
@@ -32,19 +37,17 @@
 namespace {
 
 constexpr int NT = TACO_DEC_THREADS;
-// The context part of an LSTM row is held as NMF full chunks plus a 64-column tail (one register),
-// which covers memory widths up to 576 at 3 registers fewer per row than three full chunks.
+// The context part of an LSTM row holds the row's folded context weights G[row][s], one column per
+// input position: NMF chunks cover TACO_MAX_TIN positions.
 constexpr int NMF = 2;
-constexpr int CTX_TAIL0 = NMF * TACO_CHUNK;         // first column of the tail
-constexpr int TACO_M_LSTM_MAX = CTX_TAIL0 + 64;     // 576
-constexpr int CH_A = TACO_NP + NMF + TACO_NA;       // 7 full chunks per attention-LSTM row (+ tail)
-constexpr int CH_D = TACO_NA + NMF + TACO_ND;       // 10 full chunks per decoder-LSTM row (+ tail)
+static_assert(NMF * TACO_CHUNK == TACO_MAX_TIN, "folded context chunks must cover the position capacity");
+constexpr int CH_A = TACO_NP + NMF + TACO_NA;       // 7 chunks per attention-LSTM row
+constexpr int CH_D = TACO_NA + NMF + TACO_ND;       // 10 chunks per decoder-LSTM row
 constexpr int HALO = 16;                            // >= (K-1)/2 zero columns around the weights
 
 // LDS carve (float offsets, all multiples of 4)
 constexpr int L_XP = 0;                                        // prenet out            [256]
-constexpr int L_XCTX = L_XP + TACO_NP * TACO_CHUNK;            // attention context     [768]
-constexpr int L_XAH = L_XCTX + TACO_NM * TACO_CHUNK;           // attention hidden      [1024]
+constexpr int L_XAH = L_XP + TACO_NP * TACO_CHUNK;             // attention hidden      [1024]
 constexpr int L_XDH = L_XAH + TACO_NA * TACO_CHUNK;            // decoder hidden        [1024]
 constexpr int L_MELIN = L_XDH + TACO_ND * TACO_CHUNK;          // decoder input + gate  [128]
 constexpr int L_P1 = L_MELIN + 128;                            // prenet layer-1 out    [256]
@@ -54,18 +57,17 @@ constexpr int L_AW = L_EW + TACO_MAX_TIN;                      // attention weig
 constexpr int L_CUM = L_AW + TACO_MAX_TIN + 2 * HALO;          // cumulative weights, halo both sides
 constexpr int L_U = L_CUM + TACO_MAX_TIN + 2 * HALO;           // location term + processed memory [slots][128]
 constexpr int L_PMROW = L_U + TACO_E_SLOTS * TACO_MAX_A;       // processed-memory rows [slots][128]
-constexpr int L_MEMCOL = L_PMROW + TACO_E_SLOTS * TACO_MAX_A;  // memory columns [slots][1024]
 constexpr int TACO_W1_ROWS = TACO_MAX_MEL;                     // n_mel capacity of the replicated prenet layer 1
 
-constexpr int L_W1T = L_MEMCOL + TACO_C_SLOTS * TACO_MAX_TIN;  // prenet layer 1, transposed [n_mel][256], in EVERY workgroup
+constexpr int L_W1T = L_PMROW + TACO_E_SLOTS * TACO_MAX_A;     // prenet layer 1, transposed [n_mel][256], in EVERY workgroup
 constexpr int P1_KPARTS = TACO_DEC_THREADS / 64;               // layer 1 is split 8 ways over its input columns
 constexpr int P1_KPER = TACO_W1_ROWS / P1_KPARTS;              // 10 input columns per part
 static_assert(P1_KPER * P1_KPARTS == TACO_W1_ROWS && TACO_NP * TACO_CHUNK == 256, "layer-1 tiling");
 constexpr int L_P1HALF = L_W1T + TACO_W1_ROWS * TACO_NP * TACO_CHUNK;   // layer-1 partial sums [8][256]
 constexpr int L_W2ROW = L_P1HALF + P1_KPARTS * TACO_NP * TACO_CHUNK;   // prenet layer-2 row [256]
 constexpr int L_QROW = L_W2ROW + TACO_NP * TACO_CHUNK;         // query row [1024]
-constexpr int L_PROJROW = L_QROW + TACO_NA * TACO_CHUNK;       // projection row [1024 + 768]
-constexpr int L_LOCCONV = L_PROJROW + (TACO_ND + TACO_NM) * TACO_CHUNK;   // [F][2][K] <= 1984
+constexpr int L_PROJROW = L_QROW + TACO_NA * TACO_CHUNK;       // projection row [1024 hidden + 512 folded context]
+constexpr int L_LOCCONV = L_PROJROW + (TACO_ND + NMF) * TACO_CHUNK;       // [F][2][K] <= 1984
 constexpr int L_LOCDT = L_LOCCONV + 1984;                      // location dense, transposed [F][128]
 constexpr int L_V = L_LOCDT + TACO_MAX_F * TACO_MAX_A;         // v [128]
 constexpr int L_CONVOUT = L_V + TACO_MAX_A;                    // location conv out [slots][32]
@@ -84,7 +86,8 @@ struct DecArgs {
   int b;                 // utterance index into lens
   const float *prenet_w1, *prenet_w2, *att_w_ih, *att_w_hh, *att_b_ih, *att_b_hh, *query_w, *v_w, *loc_conv_w,
       *loc_dense_w, *dec_w_ih, *dec_w_hh, *dec_b_ih, *dec_b_hh, *proj_w, *proj_b, *gate_w, *gate_b;
-  const float *memory, *pm;
+  const float* pm;
+  const float* G;        // folded context weights [4*Ra + 4*Rd + n_mel + 1][T_in], zero at positions >= len
   const uint8_t* masks;
   int T_cap, max_steps;
   float thr;
@@ -202,8 +205,11 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
   const bool act_a = unit < Ua && gu_a < Ra;       // wave-uniform
   const bool act_d = unit < Ud && gu_d < Rd;
 
-  float wa[2][CH_A][4], wa_tail[2];
-  float wd[2][CH_D][4], wd_tail[2];
+  float wa[2][CH_A][4];
+  float wd[2][CH_D][4];
+  const float* G_att = a.G;                                  // rows in the order of att_w_ih's rows
+  const float* G_dec = a.G + (size_t)4 * Ra * a.T_in;        // then dec_w_ih's rows
+  const float* G_proj = G_dec + (size_t)4 * Rd * a.T_in;     // then the projection rows, stop-token row last
   {
     const int n_ih_a = P + M, n_ih_d = Ra + M;
 #pragma unroll
@@ -221,7 +227,7 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
               if (col < P) v = a.att_w_ih[(size_t)ra * n_ih_a + col];
             } else if (c < TACO_NP + NMF) {
               const int col = (c - TACO_NP) * TACO_CHUNK + lane * 4 + e;
-              if (col < M) v = a.att_w_ih[(size_t)ra * n_ih_a + P + col];
+              if (col < a.T_in) v = G_att[(size_t)ra * a.T_in + col];
             } else {
               const int col = (c - TACO_NP - NMF) * TACO_CHUNK + lane * 4 + e;
               if (col < Ra) v = a.att_w_hh[(size_t)ra * Ra + col];
@@ -242,7 +248,7 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
               if (col < Ra) v = a.dec_w_ih[(size_t)rd * n_ih_d + col];
             } else if (c < TACO_NA + NMF) {
               const int col = (c - TACO_NA) * TACO_CHUNK + lane * 4 + e;
-              if (col < M) v = a.dec_w_ih[(size_t)rd * n_ih_d + Ra + col];
+              if (col < a.T_in) v = G_dec[(size_t)rd * a.T_in + col];
             } else {
               const int col = (c - TACO_NA - NMF) * TACO_CHUNK + lane * 4 + e;
               if (col < Rd) v = a.dec_w_hh[(size_t)rd * Rd + col];
@@ -252,8 +258,6 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      wa_tail[r] = (act_a && CTX_TAIL0 + lane < M) ? a.att_w_ih[(size_t)ra * n_ih_a + P + CTX_TAIL0 + lane] : 0.0f;
-      wd_tail[r] = (act_d && CTX_TAIL0 + lane < M) ? a.dec_w_ih[(size_t)rd * n_ih_d + Ra + CTX_TAIL0 + lane] : 0.0f;
       if (act_a && lane == 0) lds[L_BIAS + wave * 2 + r] = a.att_b_ih[ra] + a.att_b_hh[ra];
       if (act_d && lane == 0) lds[L_BIAS + 16 + wave * 2 + r] = a.dec_b_ih[rd] + a.dec_b_hh[rd];
     }
@@ -275,7 +279,8 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
   if (own_proj) {
     const float* src = proj_row < NMEL ? a.proj_w + (size_t)proj_row * n_hc : a.gate_w;
     _Pragma("unroll 1") for (int k = tid; k < Rd; k += NT) lds[L_PROJROW + k] = src[k];
-    _Pragma("unroll 1") for (int k = tid; k < M; k += NT) lds[L_PROJROW + TACO_ND * TACO_CHUNK + k] = src[Rd + k];
+    _Pragma("unroll 1") for (int k = tid; k < a.T_in; k += NT)
+      lds[L_PROJROW + TACO_ND * TACO_CHUNK + k] = G_proj[(size_t)proj_row * a.T_in + k];
     if (tid == 0) lds[L_PROJB] = proj_row < NMEL ? a.proj_b[proj_row] : a.gate_b[0];
   }
   _Pragma("unroll 1") for (int k = tid; k < F * 2 * K; k += NT) lds[L_LOCCONV + k] = a.loc_conv_w[k];
@@ -284,7 +289,7 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
     lds[L_LOCDT + f * TACO_MAX_A + aa] = a.loc_dense_w[k];
   }
   _Pragma("unroll 1") for (int k = tid; k < A; k += NT) lds[L_V + k] = a.v_w[k];
-  // per-utterance: processed-memory rows of my positions, memory columns of my context outputs
+  // per-utterance: processed-memory rows of my positions
   for (int slot = 0; slot < TACO_E_SLOTS; ++slot) {
     const int s = (n_wg - 1 - j) + slot * n_wg;
     if (s < len)
@@ -293,11 +298,6 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
         lds[L_PMROW + slot * TACO_MAX_A + k] = v;
         lds[L_U + slot * TACO_MAX_A + k] = v;     // location term is zero before the first frame
       }
-  }
-  for (int slot = 0; slot < TACO_C_SLOTS; ++slot) {
-    const int m = j + slot * n_wg;
-    if (m < M)
-      _Pragma("unroll 1") for (int s = tid; s < len; s += NT) lds[L_MEMCOL + slot * TACO_MAX_TIN + s] = a.memory[(size_t)s * M + m];
   }
   __syncthreads();
 
@@ -479,19 +479,36 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
       }
       taco_lds_barrier();
     }
-    if (wave < TACO_C_SLOTS) {
-      const int m = j + wave * n_wg;
-      if (m < M) {
-        float acc = 0.0f;
-        for (int s = lane; s < len; s += 64)
-          acc = fmaf(lds[L_AW + HALO + s], lds[L_MEMCOL + wave * TACO_MAX_TIN + s], acc);
-        acc = taco_wave_sum(acc);
-        if (lane == 0) taco_publish_rep<TACO_REP_CTX>(g + a.lay.ctx, a.lay.ctx_cap, m, ep, acc);
+    // heartbeat: every hand-off vector of frame t except the decoder hidden state and the frame
+    // output has been consumed by this workgroup
+    if (tid == NT - 64) taco_publish_rep<TACO_REP_SMALL>(g + a.lay.beat, a.lay.beat_cap, j, ep, 0.0f);
+
+    // ============ S7: decoder LSTM; the context enters as G * w, no hand-off ============
+    TACO_STAMP(8);
+    const float* aw = lds + L_AW + HALO;          // this frame's attention weights, zero beyond len
+    if (act_d) {
+      dot_chunks<1>(wd[0] + TACO_NA, wd[1] + TACO_NA, aw, lane, acc_d);
+      if (len > TACO_CHUNK) dot_chunks<1>(wd[0] + TACO_NA + 1, wd[1] + TACO_NA + 1, aw + TACO_CHUNK, lane, acc_d);
+      const float s0 = taco_wave_sum(acc_d[0]);
+      const float s1 = taco_wave_sum(acc_d[1]);
+      if (lane == 0) {
+        lds[L_GATES + wave * 2 + 0] = s0;
+        lds[L_GATES + wave * 2 + 1] = s1;
       }
     }
+    taco_lds_barrier();
+    if (wave == 0) {
+      const float hv = lstm_cell_lanes(lds + L_GATES, lds + L_BIAS + 16, lds + L_CELLS + 4, lane);
+      const int u = lane >> 2;
+      if ((lane & 3) == 0 && u < Ud && j * Ud + u < Rd) taco_publish_rep<TACO_REP_BIG>(g + a.lay.dh, a.lay.dh_cap, j * Ud + u, ep, hv);
+    }
+    TACO_STAMP(9);
+    // meanwhile: context half of my projection row
+    float acc_p = 0.0f;
+    if (own_proj && wave == 1) acc_p = row_partial<NMF>(lds + L_PROJROW + TACO_ND * TACO_CHUNK, aw, lane);
 
-    // while the context travels: location features of my positions for the NEXT frame (they need
-    // only this frame's weights and cumulative weights, which are final now)
+    // while the decoder hidden state travels: location features of my positions for the NEXT frame
+    // (they need only this frame's weights and cumulative weights, which are final now)
     {
       // location conv: 16 lanes per filter (32 filters x 16 = all 512 threads), taps split 16 ways
       const int f = tid >> 4, part = tid & 15;
@@ -530,35 +547,6 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
       }
     }
 
-    // ============ S7: decoder LSTM ============
-    TACO_STAMP(8);
-    taco_gather<NT>(g + a.lay.ctx + (j % TACO_REP_CTX) * a.lay.ctx_cap, M, ep, lds + L_XCTX, wctx, 0x800u);
-    TACO_STAMP(9);
-    // heartbeat: every hand-off vector of frame t except the decoder hidden state and the frame
-    // output has been consumed by this workgroup
-    if (tid == NT - 64) taco_publish_rep<TACO_REP_SMALL>(g + a.lay.beat, a.lay.beat_cap, j, ep, 0.0f);
-    if (act_d) {
-      dot_chunks<NMF>(wd[0] + TACO_NA, wd[1] + TACO_NA, lds + L_XCTX, lane, acc_d);
-      const float xt = lds[L_XCTX + CTX_TAIL0 + lane];
-      acc_d[0] = fmaf(wd_tail[0], xt, acc_d[0]);
-      acc_d[1] = fmaf(wd_tail[1], xt, acc_d[1]);
-      const float s0 = taco_wave_sum(acc_d[0]);
-      const float s1 = taco_wave_sum(acc_d[1]);
-      if (lane == 0) {
-        lds[L_GATES + wave * 2 + 0] = s0;
-        lds[L_GATES + wave * 2 + 1] = s1;
-      }
-    }
-    taco_lds_barrier();
-    if (wave == 0) {
-      const float hv = lstm_cell_lanes(lds + L_GATES, lds + L_BIAS + 16, lds + L_CELLS + 4, lane);
-      const int u = lane >> 2;
-      if ((lane & 3) == 0 && u < Ud && j * Ud + u < Rd) taco_publish_rep<TACO_REP_BIG>(g + a.lay.dh, a.lay.dh_cap, j * Ud + u, ep, hv);
-    }
-    // meanwhile: context half of my projection row
-    float acc_p = 0.0f;
-    if (own_proj && wave == 1) acc_p = row_partial<TACO_NM>(lds + L_PROJROW + TACO_ND * TACO_CHUNK, lds + L_XCTX, lane);
-
     // ============ S8: mel / stop-token projection, row proj_row ============
     TACO_STAMP(10);
     taco_gather<NT>(g + a.lay.dh + (j % TACO_REP_BIG) * a.lay.dh_cap, Rd, ep, lds + L_XDH, wctx, 0x900u);
@@ -572,14 +560,13 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
         else a.gate[t] = v;
       }
     }
-    // while the frame output travels: next frame's attention-LSTM partial sums
+    // while the frame output travels: next frame's attention-LSTM partial sums over
+    // [folded context | attention hidden state]
     acc_a[0] = 0.0f;
     acc_a[1] = 0.0f;
     if (act_a) {
-      dot_chunks<NMF>(wa[0] + TACO_NP, wa[1] + TACO_NP, lds + L_XCTX, lane, acc_a);
-      const float xt = lds[L_XCTX + CTX_TAIL0 + lane];
-      acc_a[0] = fmaf(wa_tail[0], xt, acc_a[0]);
-      acc_a[1] = fmaf(wa_tail[1], xt, acc_a[1]);
+      dot_chunks<1>(wa[0] + TACO_NP, wa[1] + TACO_NP, aw, lane, acc_a);
+      if (len > TACO_CHUNK) dot_chunks<1>(wa[0] + TACO_NP + 1, wa[1] + TACO_NP + 1, aw + TACO_CHUNK, lane, acc_a);
       dot_chunks<TACO_NA>(wa[0] + TACO_NP + NMF, wa[1] + TACO_NP + NMF, lds + L_XAH, lane, acc_a);
     }
   }
@@ -606,7 +593,7 @@ static void fill_layout(taco_dec_layout& lay, int n_wg) {
   lay.ah = take(TACO_NA * TACO_CHUNK, TACO_REP_BIG, lay.ah_cap);
   lay.q = take(TACO_MAX_A, TACO_REP_SMALL, lay.q_cap);
   lay.e = take(TACO_MAX_TIN, TACO_REP_SMALL, lay.e_cap);
-  lay.ctx = take(TACO_NM * TACO_CHUNK, TACO_REP_CTX, lay.ctx_cap);
+  lay.ctx = 0; lay.ctx_cap = 0;   // the context is folded into G: no hand-off vector
   lay.dh = take(TACO_ND * TACO_CHUNK, TACO_REP_BIG, lay.dh_cap);
   lay.mel = take(128, TACO_REP_SMALL, lay.mel_cap);
   lay.beat = take(n_wg, TACO_REP_SMALL, lay.beat_cap);
@@ -622,7 +609,7 @@ size_t taco_decoder_granules(int n_wg) {
 int taco_decoder_check_dims(const taco_dims& d, int n_wg) {
   if (d.P % 4 != 0) TACO_FAIL(TACO_EINVAL, "prenet_dim %d must be a multiple of 4", d.P);
   if (d.P > TACO_NP * TACO_CHUNK || d.P > n_wg) TACO_FAIL(TACO_EINVAL, "prenet_dim %d exceeds the decoder kernel's capacity %d", d.P, TACO_NP * TACO_CHUNK < n_wg ? TACO_NP * TACO_CHUNK : n_wg);
-  if (d.M > TACO_M_LSTM_MAX || d.M > TACO_C_SLOTS * n_wg) TACO_FAIL(TACO_EINVAL, "memory width %d exceeds the decoder kernel's capacity %d", d.M, TACO_M_LSTM_MAX);
+  if (d.M > TACO_NM * TACO_CHUNK) TACO_FAIL(TACO_EINVAL, "memory width %d exceeds the decoder's capacity %d", d.M, TACO_NM * TACO_CHUNK);
   if (d.R_a > TACO_NA * TACO_CHUNK || d.R_a > TACO_UNITS_PER_WG * n_wg) TACO_FAIL(TACO_EINVAL, "attention_rnn_dim %d exceeds the decoder kernel's capacity", d.R_a);
   if (d.R_d > TACO_ND * TACO_CHUNK || d.R_d > TACO_UNITS_PER_WG * n_wg) TACO_FAIL(TACO_EINVAL, "decoder_rnn_dim %d exceeds the decoder kernel's capacity", d.R_d);
   if (d.A > TACO_MAX_A || d.A > n_wg) TACO_FAIL(TACO_EINVAL, "attention_dim %d exceeds the decoder kernel's capacity %d", d.A, TACO_MAX_A);
@@ -651,9 +638,17 @@ int taco_launch_decoder(taco_handle h, const float* memory, const float* pm, int
   a.query_w = w.query_w; a.v_w = w.v_w; a.loc_conv_w = w.loc_conv_w; a.loc_dense_w = w.loc_dense_w;
   a.dec_w_ih = w.dec_w_ih; a.dec_w_hh = w.dec_w_hh; a.dec_b_ih = w.dec_b_ih; a.dec_b_hh = w.dec_b_hh;
   a.proj_w = w.proj_w; a.proj_b = w.proj_b; a.gate_w = w.gate_w; a.gate_b = w.gate_b;
-  a.memory = memory; a.pm = pm; a.masks = masks; a.T_cap = T_cap; a.max_steps = max_steps; a.thr = thr;
+  a.pm = pm; a.G = h->ws_G; a.masks = masks; a.T_cap = T_cap; a.max_steps = max_steps; a.thr = thr;
   a.forced_mel = forced_mel; a.mel = mel; a.gate = gate; a.align = align;
   a.gran = h->dec_gran; a.lay = h->dec_lay; a.ctl = h->dec_ctl;
+
+  // folded context weights of this utterance: G = ctx_w_cat [rows][M] * memory^T [M][T_in], written as a
+  // kernel-size-1 convolution over the transposed memory (columns >= len come out as zero)
+  int rc = taco_launch_transpose(memory, h->ws_memT, T_in, d.M, s);
+  if (rc != TACO_OK) return rc;
+  rc = taco_launch_conv(h->ws_memT, h->ws_G, h->ctx_w_cat, nullptr, nullptr, nullptr, nullptr, lens ? lens + b : nullptr,
+                        1, d.M, h->ctx_rows, 1, T_in, 0, s);
+  if (rc != TACO_OK) return rc;
 
   const size_t gran_bytes = (size_t)h->dec_lay.per_parity * 2 * sizeof(taco_granule);
   TACO_HIP(hipMemsetAsync(h->dec_gran, 0, gran_bytes, s));
@@ -690,8 +685,8 @@ int taco_launch_decoder(taco_handle h, const float* memory, const float* pm, int
     TACO_HIP(hipMemcpy(st.data(), stamps_dev, stamp_count * 8, hipMemcpyDeviceToHost));
     const int nfr = (int)h->dec_ctl_host->n_frames < TACO_STAMP_FRAMES ? (int)h->dec_ctl_host->n_frames : TACO_STAMP_FRAMES;
     static const char* names[TACO_STAMP_POINTS] = {"frame top done", "S1 publish p1 + attn partial", "gather p1", "S2 + gather p",
-        "S3 attn LSTM + loc features", "gather ah", "S4 q + gather q", "S5 energies + gather e", "S6 softmax + ctx",
-        "gather ctx", "S7 dec LSTM", "gather dh"};
+        "S3 attn LSTM", "gather ah", "S4 q + gather q", "S5 energies + gather e", "S6 softmax",
+        "S7 dec LSTM", "proj half + loc features", "gather dh"};
     for (int wg = 0; wg < 2 && nfr > 8; ++wg) {
       double acc[TACO_STAMP_POINTS + 1] = {0};
       int cnt = 0;

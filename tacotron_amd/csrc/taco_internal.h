@@ -73,6 +73,13 @@ struct taco_handle_s {
   float* post_beta[TACO_MAX_CONVS];
   float* lstm_bias_sum;      // [2][4*H_e]  b_ih + b_hh of the encoder LSTM
   float* lstm_w_ih_cat;      // [2*4*H_e][E] both directions stacked
+  // Context columns of every matrix the attention context feeds, stacked row-wise:
+  // attention_rnn.weight_ih[:, P:], decoder_rnn.weight_ih[:, R_a:], linear_projection[:, R_d:],
+  // gate_layer[:, R_d:]  ->  [4*R_a + 4*R_d + n_mel + 1][M]
+  float* ctx_w_cat;
+  int ctx_rows;
+  float* ws_memT;            // [M][T_in] transposed attention memory of the utterance being decoded
+  float* ws_G;               // [ctx_rows][T_in] folded context weights G = ctx_w_cat * memory^T
   // workspaces (grow-only)
   float* ws_act[2];          // activation ping-pong [B][C_max][T]
   size_t ws_act_floats;
@@ -102,6 +109,8 @@ int taco_launch_enc_lstm(taco_handle h, const float* gx, const int32_t* lens, in
                          hipStream_t s);
 int taco_launch_memory_tail(taco_handle h, const int64_t* speakers, const int32_t* lens, int B, int T,
                             float* memory, float* pm, hipStream_t s);
+int taco_launch_transpose(const float* in, float* out, int rows, int cols, hipStream_t s);
+int taco_launch_slice_cols(const float* src, int ld, int col0, int rows, int cols, float* dst, hipStream_t s);
 int taco_launch_decoder(taco_handle h, const float* memory, const float* pm, int T_in, const int32_t* lens,
                         int b, const uint8_t* masks, int T_cap, int max_steps, float thr, const float* forced_mel,
                         float* mel, float* gate, float* align, int32_t* n_frames, uint8_t* reached,

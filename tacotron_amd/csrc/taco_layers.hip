@@ -264,7 +264,51 @@ __global__ __launch_bounds__(256) void taco_memory_tail_kernel(const TailArgs a)
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Small helpers of the folded-context GEMM: out[c][r] = in[r][c] (32 x 32 tiles through LDS), and a
+// strided column-slice copy used once per handle to stack the context columns of several matrices.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void taco_transpose_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                             int rows, int cols) {
+  __shared__ float tile[32][33];
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < rows && c < cols) ? in[(size_t)r * cols + c] : 0.0f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < cols && r < rows) out[(size_t)c * rows + r] = tile[tx][i];
+  }
+}
+
+__global__ __launch_bounds__(256) void taco_slice_cols_kernel(const float* __restrict__ src, int ld, int col0,
+                                                              int rows, int cols, float* __restrict__ dst) {
+  const size_t total = (size_t)rows * cols;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t r = i / cols;
+    const int c = (int)(i % cols);
+    dst[i] = src[r * ld + col0 + c];
+  }
+}
+
 }  // namespace
+
+int taco_launch_transpose(const float* in, float* out, int rows, int cols, hipStream_t s) {
+  hipLaunchKernelGGL(taco_transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, s, in, out, rows, cols);
+  TACO_HIP(hipGetLastError());
+  return TACO_OK;
+}
+
+int taco_launch_slice_cols(const float* src, int ld, int col0, int rows, int cols, float* dst, hipStream_t s) {
+  const size_t total = (size_t)rows * cols;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(taco_slice_cols_kernel, dim3(blocks), dim3(256), 0, s, src, ld, col0, rows, cols, dst);
+  TACO_HIP(hipGetLastError());
+  return TACO_OK;
+}
 
 int taco_launch_embed(taco_handle h, const int64_t* const* ids_dev, const int32_t* lens, int B, int T,
                       float* x, hipStream_t s) {

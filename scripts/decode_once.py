@@ -18,10 +18,14 @@ m = Tacotron2(hp, **abi.mapping_counts(ckpt, hp)); m.load_state_dict(ckpt["model
 sym, st, spk = bench.build_inputs(ckpt)
 d = lambda a: torch.from_numpy(a).to("cuda:0")
 masks = prenet_keep_masks(1111, frames, m.dims.P).to("cuda:0")
+times = []
 for _ in range(reps):
   mem, pm = m.encode([d(sym), d(st)], d(spk), None)
   out = m.decode(mem, pm, None, masks, frames, gate_threshold=2.0)
   post = m.postnet(out[0], out[3])
-torch.cuda.synchronize()
-us, fr = m.last_decode_timing()
-print(f"decode {fr} frames in {us:.1f} us = {us / fr:.2f} us/frame")
+  torch.cuda.synchronize()
+  us, fr = m.last_decode_timing()
+  times.append(us / fr)
+times = sorted(times[1:] or times)
+print(f"decode {fr} frames: min {times[0]:.2f} median {times[len(times) // 2]:.2f} max {times[-1]:.2f} us/frame "
+      f"({len(times)} timed runs) [{os.environ.get('TACO_HIP_LIB', 'product')}]")

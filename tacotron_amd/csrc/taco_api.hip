@@ -207,7 +207,6 @@ extern "C" int taco_create(const taco_dims* dims, const taco_weights* weights, i
     if (rc != TACO_OK) { taco_destroy(h); return rc; }
   }
   TACO_CREATE_HIP(hipGetLastError());
-  TACO_CREATE_HIP(hipMalloc((void**)&h->ws_memT, sizeof(float) * (size_t)d.M * TACO_MAX_TIN));
   TACO_CREATE_HIP(hipMalloc((void**)&h->ws_G, sizeof(float) * (size_t)h->ctx_rows * TACO_MAX_TIN));
 
   // ---- hand-off words, control blocks, events ----
@@ -237,7 +236,6 @@ extern "C" int taco_destroy(taco_handle h) {
   for (int i = 0; i < 2; ++i)
     if (h->ws_act[i]) (void)hipFree(h->ws_act[i]);
   if (h->ws_gx) (void)hipFree(h->ws_gx);
-  if (h->ws_memT) (void)hipFree(h->ws_memT);
   if (h->ws_G) (void)hipFree(h->ws_G);
   if (h->enc_gran) (void)hipFree(h->enc_gran);
   if (h->dec_gran) (void)hipFree(h->dec_gran);
@@ -285,13 +283,13 @@ extern "C" int taco_encode(taco_handle h, const int64_t* const* ids, const int64
   int cur = 0;
   for (int l = 0; l < d.n_enc; ++l) {
     rc = taco_launch_conv(h->ws_act[cur], h->ws_act[cur ^ 1], h->w.enc_conv_w[l], h->w.enc_conv_b[l], h->enc_alpha[l],
-                          h->enc_beta[l], nullptr, lens, B, d.E, d.E, d.k_enc, T_in, /*relu*/ 1, s);
+                          h->enc_beta[l], nullptr, lens, B, d.E, d.E, d.k_enc, T_in, /*relu*/ 1, 0, s);
     if (rc != TACO_OK) return rc;
     cur ^= 1;
   }
   // LSTM input projections of both directions for every position: a kernel-size-1 convolution
   rc = taco_launch_conv(h->ws_act[cur], h->ws_gx, h->lstm_w_ih_cat, h->lstm_bias_sum, nullptr, nullptr, nullptr, lens,
-                        B, d.E, 8 * d.H_e, 1, T_in, 0, s);
+                        B, d.E, 8 * d.H_e, 1, T_in, 0, 0, s);
   if (rc != TACO_OK) return rc;
   TACO_HIP(hipMemsetAsync(memory, 0, sizeof(float) * (size_t)B * T_in * d.M, s));
   rc = taco_launch_enc_lstm(h, h->ws_gx, lens, B, T_in, memory, s);
@@ -338,7 +336,7 @@ extern "C" int taco_postnet(taco_handle h, const float* mel, const int32_t* n_fr
     const int c_in = l == 0 ? d.n_mel : d.C_post, c_out = last ? d.n_mel : d.C_post;
     float* dst = last ? out : h->ws_act[cur];
     rc = taco_launch_conv(cur_in, dst, h->w.post_conv_w[l], h->w.post_conv_b[l], h->post_alpha[l], h->post_beta[l],
-                          last ? mel : nullptr, n_frames, B, c_in, c_out, d.k_post, T_cap, last ? 0 : /*tanh*/ 2, s);
+                          last ? mel : nullptr, n_frames, B, c_in, c_out, d.k_post, T_cap, last ? 0 : /*tanh*/ 2, 0, s);
     if (rc != TACO_OK) return rc;
     cur_in = dst;
     cur ^= 1;

@@ -642,12 +642,10 @@ int taco_launch_decoder(taco_handle h, const float* memory, const float* pm, int
   a.forced_mel = forced_mel; a.mel = mel; a.gate = gate; a.align = align;
   a.gran = h->dec_gran; a.lay = h->dec_lay; a.ctl = h->dec_ctl;
 
-  // folded context weights of this utterance: G = ctx_w_cat [rows][M] * memory^T [M][T_in], written as a
-  // kernel-size-1 convolution over the transposed memory (columns >= len come out as zero)
-  int rc = taco_launch_transpose(memory, h->ws_memT, T_in, d.M, s);
-  if (rc != TACO_OK) return rc;
-  rc = taco_launch_conv(h->ws_memT, h->ws_G, h->ctx_w_cat, nullptr, nullptr, nullptr, nullptr, lens ? lens + b : nullptr,
-                        1, d.M, h->ctx_rows, 1, T_in, 0, s);
+  // folded context weights of this utterance: G = ctx_w_cat [rows][M] * memory^T [M][T_in], run as a
+  // kernel-size-1 convolution over the position-major memory (columns >= len come out as zero)
+  const int rc = taco_launch_conv(memory, h->ws_G, h->ctx_w_cat, nullptr, nullptr, nullptr, nullptr,
+                                  lens ? lens + b : nullptr, 1, d.M, h->ctx_rows, 1, T_in, 0, /*in_time_major*/ 1, s);
   if (rc != TACO_OK) return rc;
 
   const size_t gran_bytes = (size_t)h->dec_lay.per_parity * 2 * sizeof(taco_granule);

@@ -78,7 +78,6 @@ struct taco_handle_s {
   // gate_layer[:, R_d:]  ->  [4*R_a + 4*R_d + n_mel + 1][M]
   float* ctx_w_cat;
   int ctx_rows;
-  float* ws_memT;            // [M][T_in] transposed attention memory of the utterance being decoded
   float* ws_G;               // [ctx_rows][T_in] folded context weights G = ctx_w_cat * memory^T
   // workspaces (grow-only)
   float* ws_act[2];          // activation ping-pong [B][C_max][T]
@@ -101,15 +100,15 @@ struct taco_handle_s {
 int taco_launch_embed(taco_handle h, const int64_t* const* ids_dev, const int32_t* lens, int B, int T,
                       float* x, hipStream_t s);
 // Conv1d(k, pad (k-1)/2) + per-channel affine (folded BatchNorm) + activation (+ residual).
-// in [B][c_in][T], out [B][c_out][T]; columns >= lens[b] are written as zero.
+// in [B][c_in][T] (or [B][T][c_in] when in_time_major), out [B][c_out][T]; columns >= lens[b] are
+// written as zero.
 int taco_launch_conv(const float* in, float* out, const float* w, const float* bias, const float* alpha,
                      const float* beta, const float* residual, const int32_t* lens, int B, int c_in,
-                     int c_out, int k, int T, int act, hipStream_t s);
+                     int c_out, int k, int T, int act, int in_time_major, hipStream_t s);
 int taco_launch_enc_lstm(taco_handle h, const float* gx, const int32_t* lens, int B, int T, float* memory,
                          hipStream_t s);
 int taco_launch_memory_tail(taco_handle h, const int64_t* speakers, const int32_t* lens, int B, int T,
                             float* memory, float* pm, hipStream_t s);
-int taco_launch_transpose(const float* in, float* out, int rows, int cols, hipStream_t s);
 int taco_launch_slice_cols(const float* src, int ld, int col0, int rows, int cols, float* dst, hipStream_t s);
 int taco_launch_decoder(taco_handle h, const float* memory, const float* pm, int T_in, const int32_t* lens,
                         int b, const uint8_t* masks, int T_cap, int max_steps, float thr, const float* forced_mel,

@@ -46,87 +46,132 @@ __global__ __launch_bounds__(256) void taco_embed_kernel(const EmbedArgs a) {
 
 // ------------------------------------------------------------------------------------------------
 // Conv1d(kernel KS, zero padding (KS-1)/2) fused with a per-channel affine (eval BatchNorm folded to
-// y*alpha+beta), an activation and an optional residual add.  One 256-thread workgroup computes a
-// 32-channel x 64-column output tile; input columns and weights are staged through LDS in slabs
-// of 8 input channels; each thread keeps a 2 x 4 register tile.
+// y*alpha+beta), an activation and an optional residual add, on the f32-input matrix cores
+// (v_mfma_f32_32x32x2_f32: exact f32, each product rounded once, same as an fmaf chain).
+//
+// The convolution is the GEMM  out[co][t] = sum_{ci,kk} w[co][ci][kk] * in[ci][t + kk - PAD].
+// One 256-thread workgroup computes a 32-channel x 64-column output tile.  Its four waves are
+// (column half) x (half of the input channels of a slab): every wave owns one 32 x 32 accumulator
+// tile and the two channel halves are added through LDS at the end.  Input columns and weights are
+// staged through LDS in slabs of CI input channels, double-buffered: the next slab's global loads
+// are in flight while the current slab's MFMAs run.
+// MFMA operand maps (32x32x2): lane l supplies A[row l&31][k = l>>5] and B[k = l>>5][col l&31]; the
+// accumulator holds column l&31, rows (r&3) + 8*(r>>2) + 4*(l>>5) in register r.
 // reference: ConvNorm (src/tacotron/layers.py:17-35) + BatchNorm1d in Encoder.inference
 // (src/tacotron/model.py:280-289) and Postnet.forward (205-211); residual add model.py:788-789.
 // ------------------------------------------------------------------------------------------------
-constexpr int CV_CO = 32, CV_TT = 64, CV_CI = 8;
+constexpr int CV_CO = 32, CV_TT = 64;
+typedef float taco_f32x16 __attribute__((ext_vector_type(16)));
 
 template <int KS>
 __global__ __launch_bounds__(256) void taco_conv_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                         const float* __restrict__ w, const float* __restrict__ bias,
                                                         const float* __restrict__ alpha, const float* __restrict__ beta,
                                                         const float* __restrict__ residual, const int32_t* lens,
-                                                        int c_in, int c_out, int T, int act) {
-  constexpr int XW = CV_TT + KS - 1;
+                                                        int c_in, int c_out, int T, int act, int in_time_major) {
+  constexpr int CI = KS == 1 ? 32 : 16;        // input channels per slab
   constexpr int PAD = (KS - 1) / 2;
-  __shared__ float xs[CV_CI][XW + 1];
-  __shared__ float ws[CV_CO][CV_CI * KS + 1];
-  const int tid = threadIdx.x;
+  constexpr int XW = CV_TT + KS - 1;           // input columns a tile needs
+  constexpr int XS = 96;                       // row stride = 32 (mod 64): the two k-lanes of an MFMA hit disjoint banks
+  constexpr int WS = CI * KS + 1;              // odd row stride: 32 rows -> 32 banks
+  constexpr int NW = (CV_CO * CI * KS + 255) / 256;
+  constexpr int NX = (CI * XW + 255) / 256;
+  static_assert(XW <= XS && 2 * CV_CO * WS >= 2 * 16 * 64, "tile geometry");
+  __shared__ float xs[2][CI][XS];
+  __shared__ float ws[2][CV_CO][WS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int thalf = wave & 1, khalf = wave >> 1;
+  const int i = lane & 31, h = lane >> 5;
   const int b = blockIdx.z;
   const int t0 = blockIdx.x * CV_TT;
   const int co0 = blockIdx.y * CV_CO;
   const int len = lens ? lens[b] : T;
-  const int co_sub = tid >> 4;       // 0..15 -> channels co_sub*2, +1
-  const int t_sub = tid & 15;        // 0..15 -> columns t_sub*4 .. +3
   const float* in_b = in + (size_t)b * c_in * T;
-  float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  taco_f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 
   if (t0 < len) {
-    for (int ci0 = 0; ci0 < c_in; ci0 += CV_CI) {
-      for (int idx = tid; idx < CV_CI * XW; idx += 256) {
+    float pw[NW], px[NX];
+    auto load_slab = [&](int ci0) {
+#pragma unroll
+      for (int n = 0; n < NW; ++n) {
+        const int idx = tid + n * 256;
+        const int co = idx / (CI * KS), rem = idx % (CI * KS);
+        const bool ok = idx < CV_CO * CI * KS && co0 + co < c_out && ci0 + rem / KS < c_in;
+        pw[n] = ok ? w[((size_t)(co0 + co) * c_in + ci0) * KS + rem] : 0.0f;
+      }
+#pragma unroll
+      for (int n = 0; n < NX; ++n) {
+        const int idx = tid + n * 256;
         const int r = idx / XW, c = idx % XW;
         const int tt = t0 + c - PAD, ci = ci0 + r;
-        xs[r][c] = (ci < c_in && tt >= 0 && tt < len) ? in_b[(size_t)ci * T + tt] : 0.0f;
+        const bool ok = idx < CI * XW && ci < c_in && tt >= 0 && tt < len;
+        px[n] = ok ? (in_time_major ? in_b[(size_t)tt * c_in + ci] : in_b[(size_t)ci * T + tt]) : 0.0f;
       }
-      for (int idx = tid; idx < CV_CO * CV_CI * KS; idx += 256) {
-        const int co = idx / (CV_CI * KS), rem = idx % (CV_CI * KS);
-        const int ci = rem / KS, kk = rem % KS;
-        ws[co][rem] = (co0 + co < c_out && ci0 + ci < c_in)
-                          ? w[((size_t)(co0 + co) * c_in + ci0 + ci) * KS + kk] : 0.0f;
+    };
+    auto store_slab = [&](int buf) {
+#pragma unroll
+      for (int n = 0; n < NW; ++n) {
+        const int idx = tid + n * 256;
+        if (idx < CV_CO * CI * KS) ws[buf][idx / (CI * KS)][idx % (CI * KS)] = pw[n];
       }
-      __syncthreads();
 #pragma unroll
-      for (int ci = 0; ci < CV_CI; ++ci) {
-        float xv[4 + KS - 1];
+      for (int n = 0; n < NX; ++n) {
+        const int idx = tid + n * 256;
+        if (idx < CI * XW) xs[buf][idx / XW][idx % XW] = px[n];
+      }
+    };
+    const int n_slabs = (c_in + CI - 1) / CI;
+    load_slab(0);
+    store_slab(0);
+    __syncthreads();
+    for (int s = 0; s < n_slabs; ++s) {
+      const int buf = s & 1;
+      if (s + 1 < n_slabs) load_slab((s + 1) * CI);
 #pragma unroll
-        for (int i = 0; i < 4 + KS - 1; ++i) xv[i] = xs[ci][t_sub * 4 + i];
+      for (int step = 0; step < CI / 4; ++step) {
+        const int cl = khalf * (CI / 2) + step * 2 + h;    // this lane's input channel of the k-pair
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) {
-          const float w0 = ws[co_sub * 2 + 0][ci * KS + kk];
-          const float w1 = ws[co_sub * 2 + 1][ci * KS + kk];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            acc[0][i] = fmaf(w0, xv[i + kk], acc[0][i]);
-            acc[1][i] = fmaf(w1, xv[i + kk], acc[1][i]);
-          }
+          const float av = ws[buf][i][cl * KS + kk];
+          const float bv = xs[buf][cl][thalf * 32 + i + kk];
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
         }
       }
+      if (s + 1 < n_slabs) store_slab(buf ^ 1);
       __syncthreads();
     }
-  }
+    // add the two channel halves: waves 2, 3 hand their tiles to waves 0, 1 through LDS
+    float* red = &ws[0][0][0];
+    if (khalf == 1) {
 #pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const int co = co0 + co_sub * 2 + r;
-    if (co >= c_out) continue;
-    const float al = alpha ? alpha[co] : 1.0f;
-    const float be = beta ? beta[co] : 0.0f;
-    const float bi = bias ? bias[co] : 0.0f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int t = t0 + t_sub * 4 + i;
-      if (t >= T) continue;
-      float v = 0.0f;
-      if (t < len) {
-        v = (acc[r][i] + bi) * al + be;
-        if (act == 1) v = v > 0.0f ? v : 0.0f;
-        else if (act == 2) v = tanhf(v);
-        if (residual) v += residual[((size_t)b * c_out + co) * T + t];
-      }
-      out[((size_t)b * c_out + co) * T + t] = v;
+      for (int r = 0; r < 16; ++r) red[(thalf * 16 + r) * 64 + lane] = acc[r];
     }
+    __syncthreads();
+    if (khalf == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] += red[(thalf * 16 + r) * 64 + lane];
+    }
+  }
+  if (khalf != 0) return;
+  const int t = t0 + thalf * 32 + i;
+  if (t >= T) return;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    if (co >= c_out) continue;
+    float v = 0.0f;
+    if (t < len) {
+      const float al = alpha ? alpha[co] : 1.0f;
+      const float be = beta ? beta[co] : 0.0f;
+      const float bi = bias ? bias[co] : 0.0f;
+      v = (acc[r] + bi) * al + be;
+      if (act == 1) v = v > 0.0f ? v : 0.0f;
+      else if (act == 2) v = tanhf(v);
+      if (residual) v += residual[((size_t)b * c_out + co) * T + t];
+    }
+    out[((size_t)b * c_out + co) * T + t] = v;
   }
 }
 
@@ -265,25 +310,8 @@ __global__ __launch_bounds__(256) void taco_memory_tail_kernel(const TailArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
-// Small helpers of the folded-context GEMM: out[c][r] = in[r][c] (32 x 32 tiles through LDS), and a
-// strided column-slice copy used once per handle to stack the context columns of several matrices.
+// Strided column-slice copy, used once per handle to stack the context columns of several matrices.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void taco_transpose_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                             int rows, int cols) {
-  __shared__ float tile[32][33];
-  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  for (int i = ty; i < 32; i += 8) {
-    const int r = r0 + i, c = c0 + tx;
-    tile[i][tx] = (r < rows && c < cols) ? in[(size_t)r * cols + c] : 0.0f;
-  }
-  __syncthreads();
-  for (int i = ty; i < 32; i += 8) {
-    const int c = c0 + i, r = r0 + tx;
-    if (c < cols && r < rows) out[(size_t)c * rows + r] = tile[tx][i];
-  }
-}
-
 __global__ __launch_bounds__(256) void taco_slice_cols_kernel(const float* __restrict__ src, int ld, int col0,
                                                               int rows, int cols, float* __restrict__ dst) {
   const size_t total = (size_t)rows * cols;
@@ -295,12 +323,6 @@ __global__ __launch_bounds__(256) void taco_slice_cols_kernel(const float* __res
 }
 
 }  // namespace
-
-int taco_launch_transpose(const float* in, float* out, int rows, int cols, hipStream_t s) {
-  hipLaunchKernelGGL(taco_transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, s, in, out, rows, cols);
-  TACO_HIP(hipGetLastError());
-  return TACO_OK;
-}
 
 int taco_launch_slice_cols(const float* src, int ld, int col0, int rows, int cols, float* dst, hipStream_t s) {
   const size_t total = (size_t)rows * cols;
@@ -331,13 +353,13 @@ int taco_launch_embed(taco_handle h, const int64_t* const* ids_dev, const int32_
 
 int taco_launch_conv(const float* in, float* out, const float* w, const float* bias, const float* alpha,
                      const float* beta, const float* residual, const int32_t* lens, int B, int c_in,
-                     int c_out, int k, int T, int act, hipStream_t s) {
+                     int c_out, int k, int T, int act, int in_time_major, hipStream_t s) {
   const dim3 grid((T + CV_TT - 1) / CV_TT, (c_out + CV_CO - 1) / CV_CO, B);
   switch (k) {
 #define TACO_CONV_CASE(KS)                                                                          \
   case KS:                                                                                          \
     hipLaunchKernelGGL(taco_conv_kernel<KS>, grid, dim3(256), 0, s, in, out, w, bias, alpha, beta,  \
-                       residual, lens, c_in, c_out, T, act);                                        \
+                       residual, lens, c_in, c_out, T, act, in_time_major);                         \
     break;
     TACO_CONV_CASE(1)
     TACO_CONV_CASE(3)

@@ -161,9 +161,11 @@ def main():
   # process); per frame, scaled to this launch's frame count
   traffic = None
   try:
-    with open(os.path.join(ROOT, "profiles", "r1c_pmc_traffic.json")) as f:
+    import glob
+    latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]
+    with open(latest) as f:
       traffic = int(json.load(f)["hbm_bytes_per_frame"] * frames)
-  except (OSError, KeyError, ValueError):
+  except (IndexError, OSError, KeyError, ValueError):
     traffic = None
   out = {
     "metric": "mel frames/sec", "value": round(value, 1), "unit": "mel frames/s", "n_gpus": world,

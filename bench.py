@@ -76,6 +76,46 @@ def cpu_baseline(ckpt, sym, st, spk, target_s):
               ms_per_frame=round(dt / frames * 1e3, 4))
 
 
+def timed_region(steps, step, barrier, max_over_ranks):
+  """EXACTLY `steps` steps between two barriers; returns the slowest rank's seconds."""
+  barrier()
+  t0 = time.perf_counter()
+  for _ in range(steps):
+    step()
+  barrier()
+  return max_over_ranks(time.perf_counter() - t0)
+
+
+def rehearse(args, world, rank):
+  """The launch / barrier / reduction skeleton of main() with a sleep in place of the GPU step."""
+  dist = None
+  if world > 1:
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+
+  def barrier():
+    if dist is not None:
+      dist.barrier()
+
+  def max_over_ranks(seconds):
+    if dist is None:
+      return seconds
+    t = torch.tensor([seconds], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+  step_s = 0.002 * (1 + rank)                    # ranks of unequal speed: the slowest must set the time
+  for _ in range(args.warmup):
+    time.sleep(step_s)
+  elapsed = timed_region(args.steps, lambda: time.sleep(step_s), barrier, max_over_ranks)
+  if rank == 0:
+    print(json.dumps({"rehearsal": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                      "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+                      "value": round(world * args.steps * args.frames / elapsed, 1)}), flush=True)
+  if dist is not None:
+    dist.destroy_process_group()
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
@@ -83,6 +123,10 @@ def main():
   ap.add_argument("--warmup", type=int, default=3)
   ap.add_argument("--frames", type=int, default=1000, help="decoder frames per utterance (max_decoder_steps)")
   ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline sample size; 0 disables it")
+  ap.add_argument("--rehearse-ranks", action="store_true",
+                  help="no GPU work: every rank sleeps instead of synthesizing and the ranks meet over gloo; "
+                       "exercises the multi-process launch, barrier and max-over-ranks plumbing on a CPU-only machine "
+                       "(the printed line is marked rehearsal and is not a measurement)")
   args = ap.parse_args()
 
   world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -93,6 +137,8 @@ def main():
       raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
                        "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
     raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+  if args.rehearse_ranks:
+    return rehearse(args, world, rank)
   if not torch.cuda.is_available():
     raise SystemExit("bench.py needs an MI355X; there is no CPU path (the cpu_baseline leg is only a side measurement)")
   torch.cuda.set_device(local_rank)
@@ -135,17 +181,19 @@ def main():
     post, n_frames = step()
   assert int(n_frames[0]) == frames
   dec_us = []
-  barrier()
-  t0 = time.perf_counter()
-  for _ in range(args.steps):
+
+  def timed_step():
     step()
     dec_us.append(model.last_decode_timing()[0])   # decode has completed already: the call returns at once
-  barrier()
-  elapsed = time.perf_counter() - t0
-  if dist is not None:
-    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+
+  def max_over_ranks(seconds):
+    if dist is None:
+      return seconds
+    t = torch.tensor([seconds], device=device, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    return float(t.item())
+
+  elapsed = timed_region(args.steps, timed_step, barrier, max_over_ranks)
 
   total_frames = world * args.steps * frames
   value = total_frames / elapsed

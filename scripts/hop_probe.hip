@@ -73,13 +73,16 @@ __global__ void pingpong_kernel(u64* a, u64* b, int peer_block, int rounds, int 
   if (me == 0) { out_clk[0] = wall_clock64() - t0; out_clk[1] = ok ? 1 : 0; }
 }
 
+__device__ __forceinline__ u64 ld_sys(const u64* p) { return __hip_atomic_load((const gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void st_sys(u64* p, u64 v) { __hip_atomic_store((gu64*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
 // ---- 3. all-gather rounds: dense layout vs one 128-byte line per producer ---------------------------
 struct GArgs {
-  u64* gran; int n_wg, per_wg, rounds, replicas, line_per_producer, pollers, n_prod; float* out; unsigned* fail;
+  u64* gran; int n_wg, per_wg, rounds, replicas, line_per_producer, pollers, n_prod, sys_scope; float* out; unsigned* fail;
 };
 
-__device__ __forceinline__ float wait_val(const u64* p, unsigned ep, unsigned* fail) {
-  u64 w = ld(p);
+__device__ __forceinline__ float wait_val(const u64* p, unsigned ep, unsigned* fail, int sys_scope = 0) {
+  u64 w = sys_scope ? ld_sys(p) : ld(p);
   unsigned spins = 0;
   while ((unsigned)(w >> 32) != ep) {
     __builtin_amdgcn_s_sleep(1);
@@ -87,7 +90,7 @@ __device__ __forceinline__ float wait_val(const u64* p, unsigned ep, unsigned* f
       if (__hip_atomic_load((__attribute__((address_space(1))) unsigned*)fail, RLX_AGENT) != 0u) return 0.0f;
       if (spins > SPIN_CAP) { __hip_atomic_store((__attribute__((address_space(1))) unsigned*)fail, 1u, RLX_AGENT); return 0.0f; }
     }
-    w = ld(p);
+    w = sys_scope ? ld_sys(p) : ld(p);
   }
   return __uint_as_float((unsigned)w);
 }
@@ -109,12 +112,14 @@ __global__ __launch_bounds__(512) void gather_kernel(const GArgs a) {
     if (j < a.n_prod && tid < a.per_wg * a.replicas) {       // one lane per (granule, replica): a single store instruction
       const int k = tid % a.per_wg, c = tid / a.per_wg;
       const float v = carry * 0.5f + (float)k;
-      st(g + (size_t)c * rep_stride + slot_of(a, j, k), ((u64)ep << 32) | (u64)__float_as_uint(v));
+      const u64 word = ((u64)ep << 32) | (u64)__float_as_uint(v);
+      if (a.sys_scope & 2) st_sys(g + (size_t)c * rep_stride + slot_of(a, j, k), word);
+      else st(g + (size_t)c * rep_stride + slot_of(a, j, k), word);
     }
     const u64* src = g + (size_t)(j % a.replicas) * rep_stride;
     if (tid < a.pollers)
       for (int idx = tid; idx < n; idx += a.pollers)
-        vec[idx] = wait_val(src + slot_of(a, idx / a.per_wg, idx % a.per_wg), ep, a.fail);
+        vec[idx] = wait_val(src + slot_of(a, idx / a.per_wg, idx % a.per_wg), ep, a.fail, a.sys_scope & 1);
     __syncthreads();
     carry = vec[(j * 7 + r) % n] * 0.25f + vec[(j + 1) % n] * 0.125f;
     __syncthreads();
@@ -157,26 +162,29 @@ int main() {
     printf("ping-pong %-32s one way %7.1f ns%s\n", c.name, (double)h[0] * 10.0 / rounds / 2.0, h[1] ? "" : "  (TIMEOUT)");
   }
 
-  struct { int per_wg, replicas, lpp, pollers, n_prod; const char* name; } gc[] = {
-      {4, 2, 0, 512, 256, "256 producers x 4, dense R=2"}, {1, 8, 0, 512, 256, "256 producers x 1, dense R=8"},
-      {1, 8, 0, 512, 128, "128 producers x 1, dense R=8"}, {2, 8, 0, 512, 128, "128 producers x 2, dense R=8"},
-      {4, 8, 0, 512, 64, "64 producers x 4, dense R=8"}, {8, 8, 0, 512, 32, "32 producers x 8, dense R=8"},
-      {8, 4, 1, 512, 32, "32 producers x 8, line/producer R=4"}, {16, 4, 1, 512, 16, "16 producers x 16, line/producer R=4"},
-      {16, 8, 0, 512, 16, "16 producers x 16, dense R=8"}, {16, 8, 0, 512, 8, "8 producers x 16, dense R=8"},
-      {8, 8, 0, 512, 8, "8 producers x 8, dense R=8"}, {1, 8, 0, 512, 1, "1 producer x 1, R=8"},
-      {1, 8, 0, 128, 128, "128 producers x 1, 128 pollers"}, {1, 8, 0, 64, 64, "64 producers x 1, 64 pollers"}};
+  struct { int per_wg, replicas, n_prod, scope, mem; const char* name; } gc[] = {
+      {4, 2, 256, 0, 0, "256x4 R=2 agent/agent, hipMalloc"}, {4, 2, 256, 3, 0, "256x4 R=2 system/system, hipMalloc"},
+      {4, 2, 256, 1, 0, "256x4 R=2 agent store, system load"}, {4, 2, 256, 0, 1, "256x4 R=2 agent, fine-grained"},
+      {4, 2, 256, 3, 1, "256x4 R=2 system, fine-grained"}, {4, 2, 256, 0, 2, "256x4 R=2 agent, uncached"},
+      {4, 2, 256, 3, 2, "256x4 R=2 system, uncached"},
+      {1, 8, 256, 0, 0, "256x1 R=8 agent, hipMalloc"}, {1, 8, 256, 0, 1, "256x1 R=8 agent, fine-grained"},
+      {1, 8, 256, 0, 2, "256x1 R=8 agent, uncached"}, {1, 1, 256, 0, 2, "256x1 R=1 agent, uncached"},
+      {4, 1, 256, 0, 2, "256x4 R=1 agent, uncached"}, {8, 8, 32, 0, 2, "32x8 R=8 agent, uncached"}, {8, 1, 32, 0, 2, "32x8 R=1 agent, uncached"}};
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  u64* gran;
   const size_t max_gran = (size_t)2 * 8 * 4096;
-  hipMalloc((void**)&gran, max_gran * 8);
+  u64* gmem[3] = {nullptr, nullptr, nullptr};
+  hipMalloc((void**)&gmem[0], max_gran * 8);
+  if (hipExtMallocWithFlags((void**)&gmem[1], max_gran * 8, hipDeviceMallocFinegrained) != hipSuccess) gmem[1] = nullptr;
+  if (hipExtMallocWithFlags((void**)&gmem[2], max_gran * 8, hipDeviceMallocUncached) != hipSuccess) gmem[2] = nullptr;
   for (auto& c : gc) {
     GArgs a;
-    a.gran = gran; a.n_wg = 256; a.per_wg = c.per_wg; a.rounds = 2000; a.replicas = c.replicas; a.line_per_producer = c.lpp;
-    a.pollers = c.pollers; a.n_prod = c.n_prod; a.out = out; a.fail = fail;
+    if (!gmem[c.mem]) { printf("all-gather %-40s (allocation kind unavailable)\n", c.name); continue; }
+    a.gran = gmem[c.mem]; a.n_wg = 256; a.per_wg = c.per_wg; a.rounds = 2000; a.replicas = c.replicas; a.line_per_producer = 0;
+    a.pollers = 512; a.n_prod = c.n_prod; a.sys_scope = c.scope; a.out = out; a.fail = fail;
     float best = 1e30f;
     for (int rep = 0; rep < 3; ++rep) {
-      hipMemsetAsync(gran, 0, max_gran * 8, 0);
+      hipMemsetAsync(a.gran, 0, max_gran * 8, 0);
       hipMemsetAsync(fail, 0, 4, 0);
       hipEventRecord(e0, 0);
       hipLaunchKernelGGL(gather_kernel, dim3(256), dim3(512), 0, 0, a);

@@ -100,11 +100,11 @@ struct taco_handle_s {
 int taco_launch_embed(taco_handle h, const int64_t* const* ids_dev, const int32_t* lens, int B, int T,
                       float* x, hipStream_t s);
 // Conv1d(k, pad (k-1)/2) + per-channel affine (folded BatchNorm) + activation (+ residual).
-// in [B][c_in][T] (or [B][T][c_in] when in_time_major), out [B][c_out][T]; columns >= lens[b] are
-// written as zero.
+// in [B][c_in][T], out [B][c_out][T]; layout bit 0: in is [B][T][c_in], bit 1: out is [B][T][c_out];
+// columns >= lens[b] are written as zero.
 int taco_launch_conv(const float* in, float* out, const float* w, const float* bias, const float* alpha,
                      const float* beta, const float* residual, const int32_t* lens, int B, int c_in,
-                     int c_out, int k, int T, int act, int in_time_major, hipStream_t s);
+                     int c_out, int k, int T, int act, int layout, hipStream_t s);
 int taco_launch_enc_lstm(taco_handle h, const float* gx, const int32_t* lens, int B, int T, float* memory,
                          hipStream_t s);
 int taco_launch_memory_tail(taco_handle h, const int64_t* speakers, const int32_t* lens, int B, int T,

@@ -68,7 +68,8 @@ __global__ __launch_bounds__(256) void taco_conv_kernel(const float* __restrict_
                                                         const float* __restrict__ w, const float* __restrict__ bias,
                                                         const float* __restrict__ alpha, const float* __restrict__ beta,
                                                         const float* __restrict__ residual, const int32_t* lens,
-                                                        int c_in, int c_out, int T, int act, int in_time_major) {
+                                                        int c_in, int c_out, int T, int act, int layout) {
+  const bool in_time_major = layout & 1, out_time_major = layout & 2;   // [T][C] instead of [C][T]
   constexpr int CI = KS == 1 ? 32 : 16;        // input channels per slab
   constexpr int PAD = (KS - 1) / 2;
   constexpr int XW = CV_TT + KS - 1;           // input columns a tile needs
@@ -171,7 +172,8 @@ __global__ __launch_bounds__(256) void taco_conv_kernel(const float* __restrict_
       else if (act == 2) v = tanhf(v);
       if (residual) v += residual[((size_t)b * c_out + co) * T + t];
     }
-    out[((size_t)b * c_out + co) * T + t] = v;
+    if (out_time_major) out[((size_t)b * T + t) * c_out + co] = v;
+    else out[((size_t)b * c_out + co) * T + t] = v;
   }
 }
 
@@ -265,47 +267,34 @@ __global__ __launch_bounds__(1024) void taco_enc_lstm_kernel(const EncLstmArgs a
 }
 
 // ------------------------------------------------------------------------------------------------
-// Speaker vector concat and processed_memory = memory_layer(memory): one workgroup per (b, t).
+// Speaker vector concat (one workgroup per (b, t)); processed_memory = memory_layer(memory) follows as
+// a kernel-size-1 convolution.
 // reference: src/tacotron/model.py:779-782 (speaker concat), 403 (memory_layer, no bias).
 // ------------------------------------------------------------------------------------------------
 struct TailArgs {
   const int64_t* speakers;
   const float* spk_table;
-  const float* memory_w;   // [A][M]
   const int32_t* lens;
   float* memory;           // [B][T][M]
-  float* pm;               // [B][T][A]
-  int T, M, A, S, H2, spk_rows;
+  int T, M, S, H2, spk_rows;
 };
 
 __global__ __launch_bounds__(256) void taco_memory_tail_kernel(const TailArgs a) {
-  __shared__ float row[TACO_NM * TACO_CHUNK];
   const int t = blockIdx.x, b = blockIdx.y;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x;
   const int len = a.lens ? a.lens[b] : a.T;
   float* mem = a.memory + ((size_t)b * a.T + t) * a.M;
-  float* pm = a.pm + ((size_t)b * a.T + t) * a.A;
   if (t >= len) {
     for (int k = tid; k < a.M; k += 256) mem[k] = 0.0f;
-    for (int k = tid; k < a.A; k += 256) pm[k] = 0.0f;
     return;
   }
-  for (int k = tid; k < a.H2; k += 256) row[k] = mem[k];
   if (a.S > 0) {
     const int64_t id = a.speakers[(size_t)b * a.T + t];
     for (int k = tid; k < a.S; k += 256) {
       float v = 0.0f;
       if (id >= 0 && id < a.spk_rows) v = a.spk_table ? a.spk_table[(size_t)id * a.S + k] : (id == k ? 1.0f : 0.0f);
       mem[a.H2 + k] = v;
-      row[a.H2 + k] = v;
     }
-  }
-  __syncthreads();
-  for (int aa = wave; aa < a.A; aa += 4) {
-    float acc = 0.0f;
-    for (int k = lane; k < a.M; k += 64) acc = fmaf(a.memory_w[(size_t)aa * a.M + k], row[k], acc);
-    acc = taco_wave_sum(acc);
-    if (lane == 0) pm[aa] = acc;
   }
 }
 
@@ -353,13 +342,13 @@ int taco_launch_embed(taco_handle h, const int64_t* const* ids_dev, const int32_
 
 int taco_launch_conv(const float* in, float* out, const float* w, const float* bias, const float* alpha,
                      const float* beta, const float* residual, const int32_t* lens, int B, int c_in,
-                     int c_out, int k, int T, int act, int in_time_major, hipStream_t s) {
+                     int c_out, int k, int T, int act, int layout, hipStream_t s) {
   const dim3 grid((T + CV_TT - 1) / CV_TT, (c_out + CV_CO - 1) / CV_CO, B);
   switch (k) {
 #define TACO_CONV_CASE(KS)                                                                          \
   case KS:                                                                                          \
     hipLaunchKernelGGL(taco_conv_kernel<KS>, grid, dim3(256), 0, s, in, out, w, bias, alpha, beta,  \
-                       residual, lens, c_in, c_out, T, act, in_time_major);                         \
+                       residual, lens, c_in, c_out, T, act, layout);                                    \
     break;
     TACO_CONV_CASE(1)
     TACO_CONV_CASE(3)
@@ -402,10 +391,12 @@ int taco_launch_memory_tail(taco_handle h, const int64_t* speakers, const int32_
   if (d.M > TACO_NM * TACO_CHUNK) TACO_FAIL(TACO_EINVAL, "memory width %d too large", d.M);
   if (d.S > 0 && !speakers) TACO_FAIL(TACO_EINVAL, "speakers is NULL but the checkpoint models speakers");
   TailArgs a;
-  a.speakers = speakers; a.spk_table = h->w.spk_table; a.memory_w = h->w.memory_w; a.lens = lens;
-  a.memory = memory; a.pm = pm; a.T = T; a.M = d.M; a.A = d.A; a.S = d.S; a.H2 = 2 * d.H_e;
+  a.speakers = speakers; a.spk_table = h->w.spk_table; a.lens = lens;
+  a.memory = memory; a.T = T; a.M = d.M; a.S = d.S; a.H2 = 2 * d.H_e;
   a.spk_rows = d.spk_rows;
   hipLaunchKernelGGL(taco_memory_tail_kernel, dim3(T, B), dim3(256), 0, s, a);
   TACO_HIP(hipGetLastError());
-  return TACO_OK;
+  // processed_memory = memory_layer(memory): a kernel-size-1 convolution, position-major in and out
+  return taco_launch_conv(memory, pm, h->w.memory_w, nullptr, nullptr, nullptr, nullptr, lens, B, d.M, d.A, 1, T, 0,
+                          /*position-major in and out*/ 3, s);
 }

@@ -79,3 +79,20 @@ def test_a_failing_rank_is_reported_on_every_rank_without_a_hang():
   assert res.returncode == 0, res.stdout + res.stderr
   assert "rank 0 raised RuntimeError: rank 1 failed" in res.stdout
   assert "rank 1 raised ValueError: boom on rank 1" in res.stdout
+
+
+def test_bench_rank_plumbing_rehearsal():
+  """bench.py's multi-process skeleton (launch by torch.distributed.run, barriers, max over ranks, one
+  JSON line from rank 0) with sleeps in place of GPU work: the slowest rank must set the step time."""
+  import json
+  env = dict(os.environ, OMP_NUM_THREADS="1", PYTHONPATH=ROOT)
+  cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+         "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1",
+         "--rehearse-ranks"]
+  res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=120)
+  assert res.returncode == 0, res.stdout + res.stderr
+  lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+  assert len(lines) == 1
+  out = json.loads(lines[0])
+  assert out["n_gpus"] == 2 and out["steps"] == 5 and out["rehearsal"] is True
+  assert out["ms_per_step"] >= 4.0          # rank 1 sleeps 4 ms per step, rank 0 only 2 ms

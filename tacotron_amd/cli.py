@@ -1,6 +1,8 @@
-"""``synthesize``: every line of a text file -> one mel spectrogram ``.npy`` file.
+"""``synthesize``: every line of a text file -> one mel spectrogram ``.npy`` file;
+``synthesize-grids``: every ``.TextGrid`` file of a folder -> one ``.npy`` file.
 
     python -m tacotron_amd.cli synthesize CHECKPOINT TEXT [options]
+    python -m tacotron_amd.cli synthesize-grids CHECKPOINT DIRECTORY TIER [options]
 
 Mirrors the flags, line/paragraph numbering and output naming of the reference's ``synthesize``
 command (reference: src/tacotron_cli/inference.py:31-306), so that tools consuming its output
@@ -356,11 +358,127 @@ def synthesize_ns(ns: argparse.Namespace, synthesizer_factory: Optional[Callable
   return True
 
 
+# ---- synthesize-grids: one spectrogram per .TextGrid file (reference: src/tacotron_cli/textgrid_inference.py) ----
+def _existing_directory(value: str) -> Path:
+  path = Path(value)
+  if not path.is_dir():
+    raise argparse.ArgumentTypeError("Directory was not found!")
+  return path
+
+
+def init_grid_synthesis_parser(parser: argparse.ArgumentParser) -> Callable[[argparse.Namespace], bool]:
+  parser.description = "Synthesize each .TextGrid file into a mel-spectrogram."
+  parser.add_argument("checkpoint", metavar="CHECKPOINT", type=_existing_file,
+                      help="path to checkpoint that should be used for synthesis")
+  parser.add_argument("directory", metavar="DIRECTORY", type=_existing_directory,
+                      help="path to folder containing .TextGrid files that should be synthesized")
+  parser.add_argument("tier", metavar="TIER", type=_non_empty, help="tier containing the symbols in separate intervals")
+  parser.add_argument("--speaker", type=_non_empty, default=None,
+                      help="use that speaker for syntheses; defaults to the first speaker if left unset")
+  parser.add_argument("--max-decoder-steps", type=_positive_integer, metavar="MAX-DECODER-STEPS",
+                      default=DEFAULT_MAX_DECODER_STEPS, help="maximum step count before synthesis is stopped")
+  parser.add_argument("--batch-size", type=_positive_integer, default=1,
+                      help="grids synthesized together in one padded batch (1 = one by one, as the reference)")
+  parser.add_argument("--seed", type=_non_negative_integer, default=None,
+                      help="custom seed used for synthesis; if left unset a random seed will be chosen")
+  parser.add_argument("--device", type=str, metavar="DEVICE", default=DEFAULT_DEVICE,
+                      help="use this device, e.g., \"cuda:0\"; with one process per GPU the local rank selects it")
+  parser.add_argument("--custom-hparams", type=_non_empty, metavar="CUSTOM-HYPERPARAMETERS", default=None,
+                      help="custom hyperparameters comma separated")
+  parser.add_argument("--encoding", type=_codec, default="UTF-8", help="encoding of .TextGrid files")
+  parser.add_argument("-out", "--output-directory", type=Path, default=None, help="custom output directory")
+  return synthesize_grids_ns
+
+
+def synthesize_grids_ns(ns: argparse.Namespace, synthesizer_factory: Optional[Callable] = None,
+                        checkpoint_loader: Optional[Callable] = None) -> bool:
+  """Every ``*.TextGrid`` below DIRECTORY (any depth, suffix compared case-insensitively) becomes
+  ``<same relative folder>/<stem>.npy`` below the output directory; the symbols are the interval
+  marks of the first tier called TIER.  Unreadable grids and grids without that tier are reported
+  and skipped (reference: textgrid_inference.py:59-167)."""
+  from tacotron_amd import textgrid_io
+  log = logging.getLogger(__name__)
+  if checkpoint_loader is None:
+    from tacotron_amd.checkpoint import load_checkpoint as checkpoint_loader
+  try:
+    checkpoint = checkpoint_loader(ns.checkpoint)
+  except Exception as ex:  # pylint: disable=broad-except
+    log.debug(ex)
+    log.error("Checkpoint couldn't be loaded!")
+    return False
+
+  speaker_mapping = checkpoint.get("speaker_mapping") or {}
+  if ns.speaker is not None:
+    speaker = ns.speaker
+    if speaker not in speaker_mapping:
+      speaker = ns.speaker.split(";")[0]        # "name;accent"-style ids fall back to their first part
+      if speaker not in speaker_mapping:
+        log.error(f"Speaker \"{ns.speaker}\" doesn't exist!")
+        return False
+  else:
+    speaker = next(iter(speaker_mapping.keys())) if speaker_mapping else None
+  log.info(f"Speaker: \"{speaker}\"")
+
+  output_directory = ns.output_directory if ns.output_directory is not None else ns.directory
+  if output_directory.is_file():
+    log.error("Output directory is a file!")
+    return False
+
+  device, group = _init_ranks(ns.device)
+  rank, n_ranks = sharding.world()
+  seed = ns.seed
+  if seed is None:
+    seed = random.randint(1, 9999)
+    if n_ranks > 1:
+      import torch.distributed as dist
+      box = [seed]
+      dist.broadcast_object_list(box, src=0, group=group)
+      seed = box[0]
+  log.info(f"Seed: {seed}")
+
+  grid_paths = sorted(Path(root) / name for root, _, files in os.walk(ns.directory) for name in files
+                      if Path(name).suffix.lower() == ".textgrid")
+  plan: List[PlannedLine] = []
+  for nr, grid_path in enumerate(grid_paths, start=1):
+    try:
+      tiers = textgrid_io.read_textgrid(grid_path, ns.encoding)
+    except Exception as ex:  # pylint: disable=broad-except
+      log.error(f"File \"{grid_path.absolute()}\" couldn't be read! Skipped.")
+      log.debug(ex)
+      continue
+    tier = textgrid_io.first_tier(tiers, ns.tier)
+    if tier is None or tier.tier_class != "IntervalTier":
+      log.error(f"File \"{grid_path.absolute()}\" has no tier \"{ns.tier}\"! Skipped.")
+      continue
+    folder = output_directory / grid_path.relative_to(ns.directory).parent
+    plan.append(PlannedLine(nr, nr, list(tier.marks), folder, grid_path.stem))
+
+  if synthesizer_factory is None:
+    from tacotron_amd.synthesizer import Synthesizer as synthesizer_factory
+  synth = synthesizer_factory(checkpoint, parse_hparams_string(ns.custom_hparams), device)
+  log.info("Inferring...")
+  records = synthesize_plan(synth, plan, speaker, seed, ns.max_decoder_steps, False, ns.batch_size, group)
+  if records is None:
+    return True
+  unknown: Set[str] = set()
+  for rec in records:
+    log.info(f"Saved output to: \"{rec['path']}\" (spectrogram duration: {rec['duration_s']:.2f}s)")
+    if rec["reached_max"]:
+      log.warning("Reached max decoder steps!")
+    unknown.update(rec["unmappable"])
+  if unknown:
+    log.warning(f"Unknown symbols: {' '.join(sorted(unknown))} (#{len(unknown)})")
+  log.info(f"Written output to: \"{output_directory.absolute()}\"")
+  return True
+
+
 def build_parser() -> argparse.ArgumentParser:
   parser = argparse.ArgumentParser(prog="tacotron-amd", description="Tacotron 2 mel synthesis on MI355X")
   sub = parser.add_subparsers(dest="command", required=True)
   handler = init_synthesis_parser(sub.add_parser("synthesize"))
   sub.choices["synthesize"].set_defaults(handler=handler)
+  handler = init_grid_synthesis_parser(sub.add_parser("synthesize-grids"))
+  sub.choices["synthesize-grids"].set_defaults(handler=handler)
   parser.add_argument("-v", "--verbose", action="store_true")
   return parser
 

@@ -154,8 +154,10 @@ extern "C" int taco_create(const taco_dims* dims, const taco_weights* weights, i
   const size_t n_wcat = (size_t)8 * d.H_e * d.E, n_bsum = (size_t)8 * d.H_e;
   h->ctx_rows = 4 * d.R_a + 4 * d.R_d + d.n_mel + 1;
   const size_t n_ctxw = (size_t)h->ctx_rows * d.M;
+  const int fold_rows = TACO_MAX_A + 4;                      // a quad of dimensions may reach past A: zero rows
+  const size_t n_fold = (size_t)fold_rows * 2 * d.K;
   h->pool_floats = plan.total + n_bn_enc + n_bn_post + (n_wcat + 63) / 64 * 64 + (n_bsum + 63) / 64 * 64 +
-                   (n_ctxw + 63) / 64 * 64;
+                   (n_ctxw + 63) / 64 * 64 + (n_fold + 63) / 64 * 64;
   if (hipMalloc((void**)&h->pool, h->pool_floats * sizeof(float)) != hipSuccess) {
     delete h;
     TACO_FAIL(TACO_ENOMEM, "hipMalloc of %zu bytes for the weight pool failed", h->pool_floats * sizeof(float));
@@ -206,6 +208,9 @@ extern "C" int taco_create(const taco_dims* dims, const taco_weights* weights, i
     if (rc == TACO_OK) rc = taco_launch_slice_cols(hw.gate_w, d.R_d + d.M, d.R_d, 1, d.M, dst, 0);
     if (rc != TACO_OK) { taco_destroy(h); return rc; }
   }
+  h->loc_fold = cur; cur += (n_fold + 63) / 64 * 64;
+  rc = taco_launch_loc_fold(hw.loc_dense_w, hw.loc_conv_w, d.A, d.F, d.K, fold_rows, h->loc_fold, 0);
+  if (rc != TACO_OK) { taco_destroy(h); return rc; }
   TACO_CREATE_HIP(hipGetLastError());
   TACO_CREATE_HIP(hipMalloc((void**)&h->ws_G, sizeof(float) * (size_t)h->ctx_rows * TACO_MAX_TIN));
 

@@ -9,11 +9,8 @@
 // FLOPs.  Design:
 //   * one workgroup of 512 threads per CU (256 workgroups), resident for the whole utterance;
 //   * both LSTM weight matrices stay in VGPRs for the whole launch: workgroup j owns hidden units
-//     4j..4j+3 of each LSTM, wave w holds two gate rows (2*(w&1), +1) of unit (w>>1) - 2*(32+44)
-//     registers per lane, laid out so a lane's 4 weights of a chunk meet one ds_read_b128 of the
-//     activation vector (each 16-byte read feeds both rows);
-//   * the small matrices (prenet, query, location, projection) are spread one row per workgroup and
-//     kept in LDS; per-utterance attention memory columns / processed-memory rows likewise;
+//     4j..4j+3 of each LSTM, wave w holds two gate rows (2*(w&1), +1) of unit (w>>1), laid out so a
+//     lane's 4 weights of a chunk meet one ds_read_b128 of the activation vector;
 //   * workgroups exchange activation vectors through 8-byte {epoch, fp32} granules written with
 //     agent-scope (write-through) stores and polled with agent-scope loads: the value is its own
 //     ready flag, so no grid barrier and no cache fence sits between the dependent steps;
@@ -22,12 +19,24 @@
 //     G = W_ctx * memory^T is computed once per utterance (a GEMM before this launch); the kernel keeps
 //     its G rows where the context columns of the weight rows would sit (registers / LDS) and
 //     multiplies them with the attention weights every workgroup already has after its softmax;
+//   * an all-gather costs the more the more workgroups produce and consume it, so the small matrices
+//     live in three small groups of producer workgroups, and a frame's chain of hand-offs is
+//       decoder hidden (all 256) -> M group (27: projection / stop-token rows, 3 each)
+//       frame output (M)         -> P group (32: prenet layer 1 replicated among them, 8 layer-2 rows each)
+//       prenet output (P)        -> all: attention LSTM
+//       attention hidden (all)   -> Q group (8: 16 query rows each, the location term and the energy
+//                                   partial sums of their 16 attention dimensions for EVERY position)
+//       energy partials (Q)      -> all: sum of the 8 partials, softmax, decoder LSTM with G * w
+//     five dependent hand-offs per frame, three of them with a small group on one side;
+//   * the location layers are folded into one filter per attention dimension, E = dense * conv
+//     (computed once per model), so a Q workgroup needs no intermediate and reads E through scalar loads;
 //   * everything that does not depend on the value being waited for (the recurrent halves of the
-//     LSTM dot products, location features) is computed before the wait.
-// Granule slots are double-buffered by frame parity and every workgroup publishes a per-frame
-// heartbeat that all others collect before starting the next frame, so no workgroup can run far
-// enough ahead to overwrite a word another one still has to read.  Every wait is bounded by a
-// wall-clock deadline and a global abort word, so the grid always drains.
+//     LSTM dot products, next frame's location term) is computed before the wait.
+// Granule slots are double-buffered by frame parity.  Every workgroup consumes the prenet output, the
+// attention hidden state, the energy partials and the stop token of frame t before it publishes its
+// decoder hidden state of frame t, and nothing of frame t+2 can be published before all decoder hidden
+// states of frame t+1 are out, so no word is overwritten while someone still has to read it.  Every
+// wait is bounded by a poll budget and a global abort word, so the grid always drains.
 #include "taco_device.h"
 #ifdef TACO_STAMPS
 #include <stdio.h>
@@ -37,6 +46,7 @@
 namespace {
 
 constexpr int NT = TACO_DEC_THREADS;
+constexpr int NW = NT / 64;                          // waves per workgroup
 // The context part of an LSTM row holds the row's folded context weights G[row][s], one column per
 // input position: NMF chunks cover TACO_MAX_TIN positions.
 constexpr int NMF = 2;
@@ -44,48 +54,64 @@ static_assert(NMF * TACO_CHUNK == TACO_MAX_TIN, "folded context chunks must cove
 constexpr int CH_A = TACO_NP + NMF + TACO_NA;       // 7 chunks per attention-LSTM row
 constexpr int CH_D = TACO_NA + NMF + TACO_ND;       // 10 chunks per decoder-LSTM row
 constexpr int HALO = 16;                            // >= (K-1)/2 zero columns around the weights
+constexpr int PW = TACO_NP * TACO_CHUNK;            // prenet width capacity (256)
+constexpr int QD = TACO_MAX_A / TACO_NQ_WG;         // attention dimensions per Q workgroup (16)
+static_assert(QD == 2 * NW && QD % 4 == 0, "a Q workgroup makes two query rows per wave, dimensions in quads");
 
-// LDS carve (float offsets, all multiples of 4)
+// LDS carve (float offsets, all multiples of 4): a part every workgroup has, then one region whose
+// content depends on the workgroup's group
 constexpr int L_XP = 0;                                        // prenet out            [256]
-constexpr int L_XAH = L_XP + TACO_NP * TACO_CHUNK;             // attention hidden      [1024]
+constexpr int L_XAH = L_XP + PW;                               // attention hidden      [1024]
 constexpr int L_XDH = L_XAH + TACO_NA * TACO_CHUNK;            // decoder hidden        [1024]
-constexpr int L_MELIN = L_XDH + TACO_ND * TACO_CHUNK;          // decoder input + gate  [128]
-constexpr int L_P1 = L_MELIN + 128;                            // prenet layer-1 out    [256]
-constexpr int L_Q = L_P1 + TACO_NP * TACO_CHUNK;               // processed query       [128]
-constexpr int L_EW = L_Q + TACO_MAX_A;                         // energies              [1024]
-constexpr int L_AW = L_EW + TACO_MAX_TIN;                      // attention weights, halo both sides
+constexpr int L_PE = L_XDH + TACO_ND * TACO_CHUNK;             // energy partial sums   [groups][len]
+constexpr int L_AW = L_PE + TACO_NQ_WG * TACO_MAX_TIN;         // attention weights, halo both sides
 constexpr int L_CUM = L_AW + TACO_MAX_TIN + 2 * HALO;          // cumulative weights, halo both sides
-constexpr int L_U = L_CUM + TACO_MAX_TIN + 2 * HALO;           // location term + processed memory [slots][128]
-constexpr int L_PMROW = L_U + TACO_E_SLOTS * TACO_MAX_A;       // processed-memory rows [slots][128]
-constexpr int TACO_W1_ROWS = TACO_MAX_MEL;                     // n_mel capacity of the replicated prenet layer 1
-
-constexpr int L_W1T = L_PMROW + TACO_E_SLOTS * TACO_MAX_A;     // prenet layer 1, transposed [n_mel][256], in EVERY workgroup
-constexpr int P1_KPARTS = TACO_DEC_THREADS / 64;               // layer 1 is split 8 ways over its input columns
-constexpr int P1_KPER = TACO_W1_ROWS / P1_KPARTS;              // 10 input columns per part
-static_assert(P1_KPER * P1_KPARTS == TACO_W1_ROWS && TACO_NP * TACO_CHUNK == 256, "layer-1 tiling");
-constexpr int L_P1HALF = L_W1T + TACO_W1_ROWS * TACO_NP * TACO_CHUNK;   // layer-1 partial sums [8][256]
-constexpr int L_W2ROW = L_P1HALF + P1_KPARTS * TACO_NP * TACO_CHUNK;   // prenet layer-2 row [256]
-constexpr int L_QROW = L_W2ROW + TACO_NP * TACO_CHUNK;         // query row [1024]
-constexpr int L_PROJROW = L_QROW + TACO_NA * TACO_CHUNK;       // projection row [1024 hidden + 512 folded context]
-constexpr int L_LOCCONV = L_PROJROW + (TACO_ND + NMF) * TACO_CHUNK;       // [F][2][K] <= 1984
-constexpr int L_LOCDT = L_LOCCONV + 1984;                      // location dense, transposed [F][128]
-constexpr int L_V = L_LOCDT + TACO_MAX_F * TACO_MAX_A;         // v [128]
-constexpr int L_CONVOUT = L_V + TACO_MAX_A;                    // location conv out [slots][32]
-constexpr int L_GATES = L_CONVOUT + TACO_E_SLOTS * TACO_MAX_F; // LSTM gate pre-activations [16]
+constexpr int L_GATES = L_CUM + TACO_MAX_TIN + 2 * HALO;       // LSTM gate pre-activations [16]
 constexpr int L_RED = L_GATES + 16;                            // block-reduction scratch [32]
 constexpr int L_CELLS = L_RED + 32;                            // LSTM cell states [4 + 4]
 constexpr int L_BIAS = L_CELLS + 8;                            // b_ih + b_hh of my rows [16 + 16]
-constexpr int L_PROJB = L_BIAS + 32;                           // bias of my projection row [4]
-constexpr int L_KEEP = L_PROJB + 4;                            // prenet keep bytes [2 frame parities][2 layers][256 B]
-constexpr int L_TOTAL = L_KEEP + 2 * 2 * 64;
+constexpr int L_GATE_IN = L_BIAS + 32;                         // stop token of the previous frame [4]
+constexpr int L_ROLE = L_GATE_IN + 4;
+// P group: prenet layer 1 transposed [n_mel][256], its partial sums [8][256], 8 layer-2 rows [256],
+//          decoder input [128], layer-1 output [256], keep bytes [2 parities][2 layers][256 B]
+constexpr int TACO_W1_ROWS = TACO_MAX_MEL;
+constexpr int P1_KPARTS = NW;                                  // layer 1 is split 8 ways over its input columns
+constexpr int P1_KPER = TACO_W1_ROWS / P1_KPARTS;              // 10 input columns per part
+static_assert(P1_KPER * P1_KPARTS == TACO_W1_ROWS && PW == 256, "layer-1 tiling");
+constexpr int LP_W1T = L_ROLE;
+constexpr int LP_P1HALF = LP_W1T + TACO_W1_ROWS * PW;
+constexpr int LP_W2 = LP_P1HALF + P1_KPARTS * PW;
+constexpr int LP_MELIN = LP_W2 + TACO_P_ROWS_WG * PW;
+constexpr int LP_P1 = LP_MELIN + 128;
+constexpr int LP_KEEP = LP_P1 + PW;
+constexpr int LP_END = LP_KEEP + 2 * 2 * 64;
+// Q group: 16 query rows [1024], location term + processed memory U[16][positions], v and query
+//          values of my dimensions [16 + 16], energy partials per quad of dimensions [4][positions],
+//          the folded location filter of my dimensions
+constexpr int LQ_ROWS = L_ROLE;
+constexpr int LQ_U = LQ_ROWS + QD * TACO_NA * TACO_CHUNK;
+constexpr int LQ_V = LQ_U + QD * TACO_MAX_TIN;
+constexpr int LQ_Q = LQ_V + QD;
+constexpr int LQ_PE4 = LQ_Q + QD;
+constexpr int LQ_E = LQ_PE4 + (QD / 4) * TACO_MAX_TIN;        // folded location filter as MFMA A operands [16 k-steps][64 lanes]
+constexpr int LOC_KSTEPS = (2 * TACO_MAX_K + 3) / 4;           // 16 steps of 4 taps cover 2 x 31
+static_assert(QD == 16 && LOC_KSTEPS == 16, "the location term is a 16 x 16 x (16 x 4) matrix-core product per 16 positions");
+constexpr int LQ_END = LQ_E + LOC_KSTEPS * 64;
+// M group: 3 projection rows [1024 hidden + 512 folded context], their biases [4]
+constexpr int PROJ_ROW_LEN = (TACO_ND + NMF) * TACO_CHUNK;
+constexpr int LM_ROWS = L_ROLE;
+constexpr int LM_BIAS = LM_ROWS + TACO_MEL_ROWS_WG * PROJ_ROW_LEN;
+constexpr int LM_END = LM_BIAS + 4;
+constexpr int L_TOTAL = LP_END > LQ_END ? (LP_END > LM_END ? LP_END : LM_END) : (LQ_END > LM_END ? LQ_END : LM_END);
 static_assert(L_TOTAL * 4 + 512 <= 160 * 1024, "decoder LDS carve exceeds a CU's 160 KiB");
+static_assert(TACO_P_ROWS_WG == NW && TACO_MEL_ROWS_WG < NW, "one prenet row per wave; projection rows on waves 1..");
 
 struct DecArgs {
-  int P, M, Ra, Rd, A, F, K, n_mel, T_in, n_wg, proj_off;
+  int P, M, Ra, Rd, A, F, K, n_mel, T_in, n_wg;
   const int32_t* lens;   // device, or NULL = T_in symbols
   int b;                 // utterance index into lens
-  const float *prenet_w1, *prenet_w2, *att_w_ih, *att_w_hh, *att_b_ih, *att_b_hh, *query_w, *v_w, *loc_conv_w,
-      *loc_dense_w, *dec_w_ih, *dec_w_hh, *dec_b_ih, *dec_b_hh, *proj_w, *proj_b, *gate_w, *gate_b;
+  const float *prenet_w1, *prenet_w2, *att_w_ih, *att_w_hh, *att_b_ih, *att_b_hh, *query_w, *v_w, *loc_fold,
+      *dec_w_ih, *dec_w_hh, *dec_b_ih, *dec_b_hh, *proj_w, *proj_b, *gate_w, *gate_b;
   const float* pm;
   const float* G;        // folded context weights [4*Ra + 4*Rd + n_mel + 1][T_in], zero at positions >= len
   const uint8_t* masks;
@@ -174,22 +200,21 @@ __device__ __forceinline__ float lstm_cell_lanes(const float* gates_lds, const f
 }
 
 // STD = true fixes the extents of the usual checkpoint geometry (prenet 256, both LSTMs 1024, attention
-// 128 / 32 filters / kernel 31, 80 mel channels, 256 workgroups) at compile time: fewer live scalars and
-// no bounds arithmetic in the frame loop.  STD = false takes every extent from the arguments.
+// 128 / kernel 31, 80 mel channels, 256 workgroups) at compile time: fewer live scalars and no bounds
+// arithmetic in the frame loop.  STD = false takes every extent from the arguments.
 template <bool STD>
 __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const DecArgs a) {
   const int P = STD ? 256 : a.P;
   const int Ra = STD ? 1024 : a.Ra;
   const int Rd = STD ? 1024 : a.Rd;
   const int A = STD ? 128 : a.A;
-  const int F = STD ? 32 : a.F;
   const int K = STD ? 31 : a.K;
   const int NMEL = STD ? 80 : a.n_mel;
   const int M = a.M;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction: keep it scalar
   const int j = blockIdx.x;
   const int n_wg = STD ? 256 : a.n_wg;
   const int len = a.lens ? min(a.lens[a.b], a.T_in) : a.T_in;
@@ -263,41 +288,44 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
     }
   }
 
-  const bool own_prenet = j < P;
-  const bool own_q = j < A;
-  const int proj_row = j - a.proj_off;
-  const bool own_proj = proj_row >= 0 && proj_row <= NMEL;   // row n_mel is the stop-token row
+  // Groups (disjoint): P = workgroups [0, n_p_wg), Q = the next n_q_wg, M = the next n_m_wg.
+  const int n_p_wg = (P + TACO_P_ROWS_WG - 1) / TACO_P_ROWS_WG;
+  const int qd = (A + TACO_NQ_WG - 1) / TACO_NQ_WG;            // attention dimensions per Q workgroup (<= QD)
+  const int n_q_wg = (A + qd - 1) / qd;
+  const int n_m_wg = (NMEL + 1 + TACO_MEL_ROWS_WG - 1) / TACO_MEL_ROWS_WG;
+  const int q_off = n_p_wg, m_off = n_p_wg + n_q_wg;
+  const bool is_p = j < n_p_wg;
+  const bool is_q = j >= q_off && j < m_off;
+  const bool is_m = j >= m_off && j < m_off + n_m_wg;
+  const int p_row = is_p ? j * TACO_P_ROWS_WG + wave : P;                          // >= P: none
+  const bool own_p = p_row < P;
+  const int q_base = is_q ? (j - q_off) * qd : 0;                                  // my first attention dimension
+  const int q_cnt = is_q ? min(qd, A - q_base) : 0;                                // my dimensions
+  const int m_row = (is_m && wave >= 1 && wave <= TACO_MEL_ROWS_WG) ? (j - m_off) * TACO_MEL_ROWS_WG + (wave - 1)
+                                                                    : NMEL + 1;    // row n_mel is the stop-token row
+  const bool own_m = m_row <= NMEL;
+  float* my_proj = lds + LM_ROWS + (wave - 1) * PROJ_ROW_LEN;                        // valid for own_m waves
   const int n_hc = Rd + M;
-  _Pragma("unroll 1") for (int k = tid; k < P * NMEL; k += NT) {        // every workgroup keeps all of layer 1
-    const int r = k / NMEL, c = k % NMEL;
-    lds[L_W1T + c * (TACO_NP * TACO_CHUNK) + r] = a.prenet_w1[k];
+  if (is_p) {
+    _Pragma("unroll 1") for (int k = tid; k < P * NMEL; k += NT) {
+      const int r = k / NMEL, c = k % NMEL;
+      lds[LP_W1T + c * PW + r] = a.prenet_w1[k];
+    }
+    if (own_p)
+      _Pragma("unroll 1") for (int k = lane; k < P; k += 64) lds[LP_W2 + wave * PW + k] = a.prenet_w2[(size_t)p_row * P + k];
   }
-  if (own_prenet)
-    _Pragma("unroll 1") for (int k = tid; k < P; k += NT) lds[L_W2ROW + k] = a.prenet_w2[(size_t)j * P + k];
-  if (own_q)
-    _Pragma("unroll 1") for (int k = tid; k < Ra; k += NT) lds[L_QROW + k] = a.query_w[(size_t)j * Ra + k];
-  if (own_proj) {
-    const float* src = proj_row < NMEL ? a.proj_w + (size_t)proj_row * n_hc : a.gate_w;
-    _Pragma("unroll 1") for (int k = tid; k < Rd; k += NT) lds[L_PROJROW + k] = src[k];
-    _Pragma("unroll 1") for (int k = tid; k < a.T_in; k += NT)
-      lds[L_PROJROW + TACO_ND * TACO_CHUNK + k] = G_proj[(size_t)proj_row * a.T_in + k];
-    if (tid == 0) lds[L_PROJB] = proj_row < NMEL ? a.proj_b[proj_row] : a.gate_b[0];
+  if (is_q) {
+    _Pragma("unroll 1") for (int k = tid; k < q_cnt * Ra; k += NT) {
+      const int r = k / Ra, c = k % Ra;
+      lds[LQ_ROWS + r * (TACO_NA * TACO_CHUNK) + c] = a.query_w[(size_t)(q_base + r) * Ra + c];
+    }
+    if (tid < q_cnt) lds[LQ_V + tid] = a.v_w[q_base + tid];
   }
-  _Pragma("unroll 1") for (int k = tid; k < F * 2 * K; k += NT) lds[L_LOCCONV + k] = a.loc_conv_w[k];
-  _Pragma("unroll 1") for (int k = tid; k < A * F; k += NT) {
-    const int aa = k / F, f = k % F;
-    lds[L_LOCDT + f * TACO_MAX_A + aa] = a.loc_dense_w[k];
-  }
-  _Pragma("unroll 1") for (int k = tid; k < A; k += NT) lds[L_V + k] = a.v_w[k];
-  // per-utterance: processed-memory rows of my positions
-  for (int slot = 0; slot < TACO_E_SLOTS; ++slot) {
-    const int s = (n_wg - 1 - j) + slot * n_wg;
-    if (s < len)
-      _Pragma("unroll 1") for (int k = tid; k < A; k += NT) {
-        const float v = a.pm[(size_t)s * A + k];
-        lds[L_PMROW + slot * TACO_MAX_A + k] = v;
-        lds[L_U + slot * TACO_MAX_A + k] = v;     // location term is zero before the first frame
-      }
+  if (own_m) {
+    const float* src = m_row < NMEL ? a.proj_w + (size_t)m_row * n_hc : a.gate_w;
+    _Pragma("unroll 1") for (int k = lane; k < Rd; k += 64) my_proj[k] = src[k];
+    _Pragma("unroll 1") for (int k = lane; k < a.T_in; k += 64) my_proj[TACO_ND * TACO_CHUNK + k] = G_proj[(size_t)m_row * a.T_in + k];
+    if (lane == 0) lds[LM_BIAS + wave] = m_row < NMEL ? a.proj_b[m_row] : a.gate_b[0];
   }
   __syncthreads();
 
@@ -309,89 +337,133 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
   const int pad = (K - 1) / 2;
   int stopped = 0;
   int t = 0;
-  // attention-LSTM partial sums over [previous context | previous hidden]: computed at the end of
+  // attention-LSTM partial sums over [folded context | previous hidden]: computed at the end of
   // each frame for the next one, in the shadow of the frame-output hand-off (zero before frame 0)
   float acc_a[2] = {0.0f, 0.0f};
   // Prenet keep bytes travel global -> LDS by LDS-DMA one frame ahead (no registers held across the
-  // frame); frame 0's are loaded here.
-  unsigned char* keep_lds = reinterpret_cast<unsigned char*>(lds + L_KEEP);
-  for (int k = tid; k < 2 * P; k += NT) keep_lds[(k / P) * 256 + (k % P)] = a.masks[k];
+  // frame); frame 0's are loaded here.  Only the P group uses them.
+  unsigned char* keep_lds = reinterpret_cast<unsigned char*>(lds + LP_KEEP);
+  if (is_p) {
+    for (int k = tid; k < 2 * P; k += NT) keep_lds[(k / P) * 256 + (k % P)] = a.masks[k];
+  }
+  // Location term + processed memory of my 16 attention dimensions for every position, on the matrix
+  // cores: U[dim][s] = pm[s][dim] + sum_{c,k} E[dim][c][k] * x_c[s + k - pad] is, per tile of 16 positions,
+  // a 16 x 16 product over the 2K taps (v_mfma_f32_16x16x4_f32: lane l supplies A[row l&15][k = l>>4] and
+  // B[k = l>>4][col l&15]; the result holds column l&15, rows 4*(l>>4) + r in register r).  A wave takes
+  // every 8th tile.  With all-zero attention weights (before frame 0) U = processed memory.
+  typedef float taco_f32x4 __attribute__((ext_vector_type(4)));
+  const int quad = wave >> 1;                    // energy partials: 4 quads of dimensions x 2 waves each
+  const int sl = tid & 127;
+  if (is_q) {
+    _Pragma("unroll 1") for (int i = tid; i < LOC_KSTEPS * 64; i += NT) {
+      const int m = i >> 6, l = i & 63;
+      const int ck = 4 * m + (l >> 4), dim = q_base + (l & 15);
+      lds[LQ_E + i] = (ck < 2 * K && (l & 15) < q_cnt) ? a.loc_fold[(size_t)dim * 2 * K + ck] : 0.0f;
+    }
+  }
+  auto update_location_term = [&]() {
+    const int col = lane & 15, kq = lane >> 4;
+    _Pragma("unroll 1") for (int s0 = wave * 16; s0 < len; s0 += NW * 16) {
+      taco_f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 2
+      for (int m = 0; m < LOC_KSTEPS; ++m) {
+        int ck = 4 * m + kq;
+        ck = ck < 2 * K ? ck : 0;                  // taps beyond 2K meet a zero in A; any valid address will do
+        const int c = ck >= K ? 1 : 0;
+        const float xv = lds[(c ? L_CUM : L_AW) + HALO + s0 + col + (ck - c * K) - pad];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[LQ_E + m * 64 + lane], xv, acc, 0, 0, 0);
+      }
+      const int s = s0 + col;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int d = 4 * kq + r;
+        const float pmv = (s < len && d < q_cnt) ? a.pm[(size_t)s * A + q_base + d] : 0.0f;
+        lds[LQ_U + d * TACO_MAX_TIN + s] = acc[r] + pmv;
+      }
+    }
+  };
+  __syncthreads();
+  if (is_q) update_location_term();
   __syncthreads();
   for (;; ++t) {
-    // ============ frame boundary: previous frame's output + every workgroup's heartbeat ============
+    // ============ frame boundary: the previous frame's output (P group) / its stop token (everyone) ============
     if (t > 0) {
       const taco_granule* gp = a.gran + (size_t)((t - 1) & 1) * a.lay.per_parity;
       const unsigned ep_prev = (unsigned)t;
-      if (tid <= NMEL) {
-        const float v = taco_wait_one(gp + a.lay.mel + (j % TACO_REP_SMALL) * a.lay.mel_cap, tid, ep_prev, wctx, 0x100u);
-        if (!forced || tid == NMEL) lds[L_MELIN + tid] = v;
-      } else if (tid >= 128 && tid < 128 + n_wg) {
-        (void)taco_wait_one(gp + a.lay.beat + (j % TACO_REP_SMALL) * a.lay.beat_cap, tid - 128, ep_prev, wctx, 0x200u);
+      const taco_granule* melv = gp + a.lay.mel + (j % TACO_REP_SMALL) * a.lay.mel_cap;
+      if (is_p) {
+        if (tid <= NMEL) {
+          const float v = taco_wait_one(melv, tid, ep_prev, wctx, 0x100u);
+          if (tid == NMEL) lds[L_GATE_IN] = v;
+          else if (!forced) lds[LP_MELIN + tid] = v;
+        }
+        if (forced && tid < NMEL) lds[LP_MELIN + tid] = a.forced_mel[(size_t)tid * a.T_cap + (t - 1)];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the keep-byte DMA issued last frame has landed
+      } else if (tid == 0) {
+        lds[L_GATE_IN] = taco_wait_one(melv, NMEL, ep_prev, wctx, 0x100u);
       }
-      if (forced && tid < NMEL) lds[L_MELIN + tid] = a.forced_mel[(size_t)tid * a.T_cap + (t - 1)];
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the keep-byte DMA issued last frame has landed
       if (__syncthreads_or(wctx.failed)) break;
-      if (!forced && taco_sigmoid(lds[L_MELIN + NMEL]) > a.thr) { stopped = 1; break; }
+      if (!forced && taco_sigmoid(lds[L_GATE_IN]) > a.thr) { stopped = 1; break; }
     }
     if (t == a.max_steps) break;
-      TACO_STAMP(0);
+    TACO_STAMP(0);
+    // Q group: this frame's location term from the previous frame's weights, while the P group works
+    if (is_q && t > 0) update_location_term();
 
     const unsigned ep = (unsigned)t + 1u;
     taco_granule* g = a.gran + (size_t)(t & 1) * a.lay.per_parity;
-    // keep-bits of the two prenet dropouts: layer 1 for the row this thread finishes, layer 2 for row j
-    constexpr int PW = TACO_NP * TACO_CHUNK;
-    const unsigned char* keep_now = keep_lds + (t & 1) * 512;
-    if (wave == NT / 64 - 1 && t + 1 < a.max_steps && lane * 4 < P) {
-      // next frame's keep bytes, fetched a frame ahead (a first-touch line comes from HBM)
-      const unsigned char* src = a.masks + (size_t)(t + 1) * 2 * P + lane * 4;
-      float* dst = lds + L_KEEP + ((t + 1) & 1) * 128;
-      typedef const __attribute__((address_space(1))) void* gptr_t;
-      typedef __attribute__((address_space(3))) void* lptr_t;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 4, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(src + P), (lptr_t)(dst + 64), 4, 0, 0);
-    }
-
-    // ============ S1: prenet layer 1, ALL rows, replicated in every workgroup (20 k MACs buy one hop) ====
-    // thread = (4 adjacent rows, one of 8 slices of the input columns); rows beyond P, columns beyond
-    // n_mel are zero in LDS
-    {
-      const int rq = lane, kp = wave;
-      float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-#pragma unroll 2
-      for (int i = 0; i < P1_KPER; ++i) {
-        const int k = kp * P1_KPER + i;
-        const float4 wv = *reinterpret_cast<const float4*>(lds + L_W1T + k * PW + rq * 4);
-        const float x = lds[L_MELIN + k];
-        acc.x = fmaf(wv.x, x, acc.x);
-        acc.y = fmaf(wv.y, x, acc.y);
-        acc.z = fmaf(wv.z, x, acc.z);
-        acc.w = fmaf(wv.w, x, acc.w);
+    if (is_p) {
+      // keep-bits of the two prenet dropouts: layer 1 for the row this thread finishes, layer 2 for my rows
+      const unsigned char* keep_now = keep_lds + (t & 1) * 512;
+      if (wave == NW - 1 && t + 1 < a.max_steps && lane * 4 < P) {
+        // next frame's keep bytes, fetched a frame ahead (a first-touch line comes from HBM)
+        const unsigned char* src = a.masks + (size_t)(t + 1) * 2 * P + lane * 4;
+        float* dst = lds + LP_KEEP + ((t + 1) & 1) * 128;
+        typedef const __attribute__((address_space(1))) void* gptr_t;
+        typedef __attribute__((address_space(3))) void* lptr_t;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(src + P), (lptr_t)(dst + 64), 4, 0, 0);
       }
-      *reinterpret_cast<float4*>(lds + L_P1HALF + kp * PW + rq * 4) = acc;
-    }
-    taco_lds_barrier();
-    if (tid < PW) {
-      float v = 0.0f;
+      // ---- S1: prenet layer 1, ALL rows, in every P workgroup (20 k MACs buy one hand-off) ----
+      // thread = (4 adjacent rows, one of 8 slices of the input columns); rows beyond P, columns beyond
+      // n_mel are zero in LDS
+      {
+        const int rq = lane, kp = wave;
+        float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll 5
+        for (int i = 0; i < P1_KPER; ++i) {
+          const int k = kp * P1_KPER + i;
+          const float4 wv = *reinterpret_cast<const float4*>(lds + LP_W1T + k * PW + rq * 4);
+          const float x = lds[LP_MELIN + k];
+          acc.x = fmaf(wv.x, x, acc.x);
+          acc.y = fmaf(wv.y, x, acc.y);
+          acc.z = fmaf(wv.z, x, acc.z);
+          acc.w = fmaf(wv.w, x, acc.w);
+        }
+        *reinterpret_cast<float4*>(lds + LP_P1HALF + kp * PW + rq * 4) = acc;
+      }
+      taco_lds_barrier();
+      if (tid < PW) {
+        float v = 0.0f;
 #pragma unroll
-      for (int i = 0; i < P1_KPARTS; ++i) v += lds[L_P1HALF + i * PW + tid];
-      v = v > 0.0f ? v : 0.0f;
-      lds[L_P1 + tid] = keep_now[tid] ? v * 2.0f : 0.0f;
+        for (int i = 0; i < P1_KPARTS; ++i) v += lds[LP_P1HALF + i * PW + tid];
+        v = v > 0.0f ? v : 0.0f;
+        lds[LP_P1 + tid] = keep_now[tid] ? v * 2.0f : 0.0f;
+      }
+      taco_lds_barrier();
+      // ---- S2: prenet layer 2, one row per wave ----
+      if (own_p) {
+        float v = taco_wave_sum(row_partial<TACO_NP>(lds + LP_W2 + wave * PW, lds + LP_P1, lane));
+        v = v > 0.0f ? v : 0.0f;
+        v = keep_now[256 + p_row] ? v * 2.0f : 0.0f;
+        taco_publish_lanes<TACO_REP_SMALL>(g + a.lay.p, a.lay.p_cap, p_row, ep, v, lane);
+      }
     }
-    taco_lds_barrier();
     TACO_STAMP(1);
-
-    // ============ S2: prenet layer 2, row j ============
-    TACO_STAMP(2);
-    if (own_prenet && wave == 0) {
-      float v = taco_wave_sum(row_partial<TACO_NP>(lds + L_W2ROW, lds + L_P1, lane));
-      v = v > 0.0f ? v : 0.0f;
-      v = keep_now[256 + j] ? v * 2.0f : 0.0f;
-      if (lane == 0) taco_publish_rep<TACO_REP_SMALL>(g + a.lay.p, a.lay.p_cap, j, ep, v);
-    }
 
     // ============ S3: attention LSTM ============
     taco_gather<NT>(g + a.lay.p + (j % TACO_REP_SMALL) * a.lay.p_cap, P, ep, lds + L_XP, wctx, 0x400u);
-    TACO_STAMP(3);
+    TACO_STAMP(2);
     if (act_a) {
       dot_chunks<TACO_NP>(wa[0], wa[1], lds + L_XP, lane, acc_a);
       const float s0 = taco_wave_sum(acc_a[0]);
@@ -407,37 +479,54 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
       const int u = lane >> 2;
       if ((lane & 3) == 0 && u < Ua && j * Ua + u < Ra) taco_publish_rep<TACO_REP_BIG>(g + a.lay.ah, a.lay.ah_cap, j * Ua + u, ep, hv);
     }
+    TACO_STAMP(3);
     // meanwhile: decoder-LSTM partial over the previous decoder hidden state
     float acc_d[2] = {0.0f, 0.0f};
     if (act_d) dot_chunks<TACO_ND>(wd[0] + TACO_NA + NMF, wd[1] + TACO_NA + NMF, lds + L_XDH, lane, acc_d);
 
-    // ============ S4: query projection, row j ============
-    TACO_STAMP(4);
+    // ============ S4: query rows and energy partial sums (Q group) ============
     taco_gather<NT>(g + a.lay.ah + (j % TACO_REP_BIG) * a.lay.ah_cap, Ra, ep, lds + L_XAH, wctx, 0x500u);
-    TACO_STAMP(5);
-    if (own_q && wave == 0) {
-      const float v = taco_wave_sum(row_partial<TACO_NA>(lds + L_QROW, lds + L_XAH, lane));
-      if (lane == 0) taco_publish_rep<TACO_REP_SMALL>(g + a.lay.q, a.lay.q_cap, j, ep, v);
-    }
-    if (act_d) dot_chunks<TACO_NA>(wd[0], wd[1], lds + L_XAH, lane, acc_d);
-
-    // ============ S5: energies of my positions ============
-    taco_gather<NT>(g + a.lay.q + (j % TACO_REP_SMALL) * a.lay.q_cap, A, ep, lds + L_Q, wctx, 0x600u);
-    TACO_STAMP(6);
-    if (wave < TACO_E_SLOTS) {
-      const int s = (n_wg - 1 - j) + wave * n_wg;
-      if (s < len) {
-        float acc = 0.0f;
-        for (int aa = lane; aa < A; aa += 64)
-          acc = fmaf(lds[L_V + aa], taco_tanh(lds[L_Q + aa] + lds[L_U + wave * TACO_MAX_A + aa]), acc);
-        acc = taco_wave_sum(acc);
-        if (lane == 0) taco_publish_rep<TACO_REP_SMALL>(g + a.lay.e, a.lay.e_cap, s, ep, acc);
+    TACO_STAMP(4);
+    if (is_q) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int row = wave * 2 + r;
+        if (row < q_cnt) {
+          const float v = taco_wave_sum(row_partial<TACO_NA>(lds + LQ_ROWS + row * (TACO_NA * TACO_CHUNK), lds + L_XAH, lane));
+          if (lane == 0) lds[LQ_Q + row] = v;
+        }
+      }
+      taco_lds_barrier();
+      // thread = (position, quad of dimensions): sum over the quad of v * tanh(q + location + processed memory)
+      if (quad * 4 < q_cnt) {
+        _Pragma("unroll 1") for (int s = sl; s < len; s += 128) {
+          float acc = 0.0f;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int d = quad * 4 + i;      // rows beyond my dimensions have v = 0 and finite U
+            acc = fmaf(lds[LQ_V + d], taco_tanh(lds[LQ_Q + d] + lds[LQ_U + d * TACO_MAX_TIN + s]), acc);
+          }
+          lds[LQ_PE4 + quad * TACO_MAX_TIN + s] = acc;
+        }
+      }
+      taco_lds_barrier();
+      {
+        const int nquad = (q_cnt + 3) / 4;
+        const int grp = j - q_off;
+        _Pragma("unroll 1") for (int it = tid; it < len * TACO_REP_PE; it += NT) {
+          const int s = it % len, rep = it / len;
+          float e = lds[LQ_PE4 + s];
+          for (int qq = 1; qq < nquad; ++qq) e += lds[LQ_PE4 + qq * TACO_MAX_TIN + s];
+          taco_publish(g + a.lay.pe + (size_t)rep * a.lay.pe_cap, grp * len + s, ep, e);
+        }
       }
     }
+    if (act_d) dot_chunks<TACO_NA>(wd[0], wd[1], lds + L_XAH, lane, acc_d);
+    TACO_STAMP(5);
 
-    // ============ S6: softmax over all positions (every workgroup), context columns of mine ============
-    taco_gather<NT>(g + a.lay.e + (j % TACO_REP_SMALL) * a.lay.e_cap, len, ep, lds + L_EW, wctx, 0x700u);
-    TACO_STAMP(7);
+    // ============ S6: energies = sum of the groups' partials; softmax over all positions (every workgroup) ============
+    taco_gather<NT>(g + a.lay.pe + (j % TACO_REP_PE) * a.lay.pe_cap, n_q_wg * len, ep, lds + L_PE, wctx, 0x700u);
+    TACO_STAMP(6);
     {
       constexpr int PER = TACO_MAX_TIN / NT;   // positions per thread
       float ev[PER], ex[PER];
@@ -445,7 +534,12 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
 #pragma unroll
       for (int i = 0; i < PER; ++i) {
         const int s = tid + i * NT;
-        ev[i] = s < len ? lds[L_EW + s] : -INFINITY;
+        ev[i] = -INFINITY;
+        if (s < len) {
+          float e = lds[L_PE + s];
+          for (int gq = 1; gq < n_q_wg; ++gq) e += lds[L_PE + gq * len + s];
+          ev[i] = e;
+        }
         wm = fmaxf(wm, ev[i]);
       }
       wm = taco_wave_max(wm);
@@ -453,7 +547,7 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
       taco_lds_barrier();
       float mx = lds[L_RED];
 #pragma unroll
-      for (int i = 1; i < NT / 64; ++i) mx = fmaxf(mx, lds[L_RED + i]);
+      for (int i = 1; i < NW; ++i) mx = fmaxf(mx, lds[L_RED + i]);
       float ws = 0.0f;
 #pragma unroll
       for (int i = 0; i < PER; ++i) {
@@ -466,7 +560,7 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
       taco_lds_barrier();
       float sum = 0.0f;
 #pragma unroll
-      for (int i = 0; i < NT / 64; ++i) sum += lds[L_RED + 16 + i];
+      for (int i = 0; i < NW; ++i) sum += lds[L_RED + 16 + i];
 #pragma unroll
       for (int i = 0; i < PER; ++i) {
         const int s = tid + i * NT;
@@ -474,17 +568,14 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
           const float wgt = ex[i] / sum;
           lds[L_AW + HALO + s] = wgt;
           lds[L_CUM + HALO + s] += wgt;
-          if (j == 0 && a.align) a.align[(size_t)t * a.T_in + s] = wgt;
+          if (j == n_wg - 1 && a.align) a.align[(size_t)t * a.T_in + s] = wgt;
         }
       }
       taco_lds_barrier();
     }
-    // heartbeat: every hand-off vector of frame t except the decoder hidden state and the frame
-    // output has been consumed by this workgroup
-    if (tid == NT - 64) taco_publish_rep<TACO_REP_SMALL>(g + a.lay.beat, a.lay.beat_cap, j, ep, 0.0f);
 
     // ============ S7: decoder LSTM; the context enters as G * w, no hand-off ============
-    TACO_STAMP(8);
+    TACO_STAMP(7);
     const float* aw = lds + L_AW + HALO;          // this frame's attention weights, zero beyond len
     if (act_d) {
       dot_chunks<1>(wd[0] + TACO_NA, wd[1] + TACO_NA, aw, lane, acc_d);
@@ -502,64 +593,25 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
       const int u = lane >> 2;
       if ((lane & 3) == 0 && u < Ud && j * Ud + u < Rd) taco_publish_rep<TACO_REP_BIG>(g + a.lay.dh, a.lay.dh_cap, j * Ud + u, ep, hv);
     }
-    TACO_STAMP(9);
-    // meanwhile: context half of my projection row
+    TACO_STAMP(8);
+    // meanwhile: folded-context half of my projection rows (M group)
     float acc_p = 0.0f;
-    if (own_proj && wave == 1) acc_p = row_partial<NMF>(lds + L_PROJROW + TACO_ND * TACO_CHUNK, aw, lane);
+    if (own_m) acc_p = row_partial<NMF>(my_proj + TACO_ND * TACO_CHUNK, aw, lane);
+    TACO_STAMP(9);
 
-    // while the decoder hidden state travels: location features of my positions for the NEXT frame
-    // (they need only this frame's weights and cumulative weights, which are final now)
-    {
-      // location conv: 16 lanes per filter (32 filters x 16 = all 512 threads), taps split 16 ways
-      const int f = tid >> 4, part = tid & 15;
-      for (int slot = 0; slot < TACO_E_SLOTS; ++slot) {
-        const int s = (n_wg - 1 - j) + slot * n_wg;
-        if (s >= len) break;
-        float acc = 0.0f;
-        if (f < F) {
-#pragma unroll 4
-          for (int kk = part; kk < 2 * K; kk += 16) {
-            const int c = kk >= K ? 1 : 0;
-            const int k = kk - c * K;
-            const float x = lds[(c ? L_CUM : L_AW) + HALO + s + k - pad];
-            acc = fmaf(lds[L_LOCCONV + (f * 2 + c) * K + k], x, acc);
-          }
-        }
-        acc = taco_sum16(acc);
-        if (part == 0 && f < F) lds[L_CONVOUT + slot * TACO_MAX_F + f] = acc;
-      }
-    }
-    taco_lds_barrier();
-    {
-      // location dense + processed memory: 4 lanes per attention dimension (128 x 4 = 512 threads)
-      const int aa = tid >> 2, fq = tid & 3;
-      for (int slot = 0; slot < TACO_E_SLOTS; ++slot) {
-        const int s = (n_wg - 1 - j) + slot * n_wg;
-        if (s >= len) break;
-        float loc = 0.0f;
-        if (aa < A) {
-#pragma unroll 4
-          for (int f = fq; f < F; f += 4)
-            loc = fmaf(lds[L_LOCDT + f * TACO_MAX_A + aa], lds[L_CONVOUT + slot * TACO_MAX_F + f], loc);
-        }
-        loc = taco_sum4(loc);
-        if (fq == 0 && aa < A) lds[L_U + slot * TACO_MAX_A + aa] = loc + lds[L_PMROW + slot * TACO_MAX_A + aa];
-      }
-    }
-
-    // ============ S8: mel / stop-token projection, row proj_row ============
-    TACO_STAMP(10);
+    // ============ S8: mel / stop-token projection rows (M group) ============
     taco_gather<NT>(g + a.lay.dh + (j % TACO_REP_BIG) * a.lay.dh_cap, Rd, ep, lds + L_XDH, wctx, 0x900u);
-    TACO_STAMP(11);
-    if (own_proj && wave == 1) {
-      acc_p += row_partial<TACO_ND>(lds + L_PROJROW, lds + L_XDH, lane);
-      const float v = taco_wave_sum(acc_p) + lds[L_PROJB];
+    TACO_STAMP(10);
+    if (own_m) {
+      acc_p += row_partial<TACO_ND>(my_proj, lds + L_XDH, lane);
+      const float v = taco_wave_sum(acc_p) + lds[LM_BIAS + wave];
+      taco_publish_lanes<TACO_REP_SMALL>(g + a.lay.mel, a.lay.mel_cap, m_row, ep, v, lane);
       if (lane == 0) {
-        taco_publish_rep<TACO_REP_SMALL>(g + a.lay.mel, a.lay.mel_cap, proj_row, ep, v);
-        if (proj_row < NMEL) a.mel[(size_t)proj_row * a.T_cap + t] = v;
+        if (m_row < NMEL) a.mel[(size_t)m_row * a.T_cap + t] = v;
         else a.gate[t] = v;
       }
     }
+    TACO_STAMP(11);
     // while the frame output travels: next frame's attention-LSTM partial sums over
     // [folded context | attention hidden state]
     acc_a[0] = 0.0f;
@@ -591,12 +643,9 @@ static void fill_layout(taco_dec_layout& lay, int n_wg) {
   };
   lay.p = take(TACO_NP * TACO_CHUNK, TACO_REP_SMALL, lay.p_cap);
   lay.ah = take(TACO_NA * TACO_CHUNK, TACO_REP_BIG, lay.ah_cap);
-  lay.q = take(TACO_MAX_A, TACO_REP_SMALL, lay.q_cap);
-  lay.e = take(TACO_MAX_TIN, TACO_REP_SMALL, lay.e_cap);
-  lay.ctx = 0; lay.ctx_cap = 0;   // the context is folded into G: no hand-off vector
+  lay.pe = take(TACO_NQ_WG * TACO_MAX_TIN, TACO_REP_PE, lay.pe_cap);
   lay.dh = take(TACO_ND * TACO_CHUNK, TACO_REP_BIG, lay.dh_cap);
   lay.mel = take(128, TACO_REP_SMALL, lay.mel_cap);
-  lay.beat = take(n_wg, TACO_REP_SMALL, lay.beat_cap);
   lay.per_parity = off;
 }
 
@@ -608,14 +657,18 @@ size_t taco_decoder_granules(int n_wg) {
 
 int taco_decoder_check_dims(const taco_dims& d, int n_wg) {
   if (d.P % 4 != 0) TACO_FAIL(TACO_EINVAL, "prenet_dim %d must be a multiple of 4", d.P);
-  if (d.P > TACO_NP * TACO_CHUNK || d.P > n_wg) TACO_FAIL(TACO_EINVAL, "prenet_dim %d exceeds the decoder kernel's capacity %d", d.P, TACO_NP * TACO_CHUNK < n_wg ? TACO_NP * TACO_CHUNK : n_wg);
+  if (d.P > TACO_NP * TACO_CHUNK) TACO_FAIL(TACO_EINVAL, "prenet_dim %d exceeds the decoder kernel's capacity %d", d.P, TACO_NP * TACO_CHUNK);
   if (d.M > TACO_NM * TACO_CHUNK) TACO_FAIL(TACO_EINVAL, "memory width %d exceeds the decoder's capacity %d", d.M, TACO_NM * TACO_CHUNK);
   if (d.R_a > TACO_NA * TACO_CHUNK || d.R_a > TACO_UNITS_PER_WG * n_wg) TACO_FAIL(TACO_EINVAL, "attention_rnn_dim %d exceeds the decoder kernel's capacity", d.R_a);
   if (d.R_d > TACO_ND * TACO_CHUNK || d.R_d > TACO_UNITS_PER_WG * n_wg) TACO_FAIL(TACO_EINVAL, "decoder_rnn_dim %d exceeds the decoder kernel's capacity", d.R_d);
-  if (d.A > TACO_MAX_A || d.A > n_wg) TACO_FAIL(TACO_EINVAL, "attention_dim %d exceeds the decoder kernel's capacity %d", d.A, TACO_MAX_A);
-  if (d.F > TACO_MAX_F) TACO_FAIL(TACO_EINVAL, "attention_location_n_filters %d exceeds %d", d.F, TACO_MAX_F);
+  if (d.A > TACO_MAX_A) TACO_FAIL(TACO_EINVAL, "attention_dim %d exceeds the decoder kernel's capacity %d", d.A, TACO_MAX_A);
+  if (d.F < 1) TACO_FAIL(TACO_EINVAL, "attention_location_n_filters %d", d.F);
   if (d.K > TACO_MAX_K || (d.K & 1) == 0) TACO_FAIL(TACO_EINVAL, "attention_location_kernel_size %d must be odd and <= %d", d.K, TACO_MAX_K);
-  if (d.n_mel > TACO_MAX_MEL || d.n_mel + 1 > n_wg) TACO_FAIL(TACO_EINVAL, "n_mel_channels %d exceeds %d", d.n_mel, TACO_MAX_MEL);
+  if (d.n_mel > TACO_MAX_MEL) TACO_FAIL(TACO_EINVAL, "n_mel_channels %d exceeds %d", d.n_mel, TACO_MAX_MEL);
+  const int qd = (d.A + TACO_NQ_WG - 1) / TACO_NQ_WG;
+  const int groups = (d.P + TACO_P_ROWS_WG - 1) / TACO_P_ROWS_WG + (d.A + qd - 1) / qd +
+                     (d.n_mel + 1 + TACO_MEL_ROWS_WG - 1) / TACO_MEL_ROWS_WG;
+  if (groups > n_wg) TACO_FAIL(TACO_EINVAL, "the decoder's producer groups need %d workgroups, the device has %d CUs", groups, n_wg);
   return TACO_OK;
 }
 
@@ -625,17 +678,16 @@ int taco_launch_decoder(taco_handle h, const float* memory, const float* pm, int
                         hipStream_t s) {
   const taco_dims& d = h->d;
   const int n_wg = h->n_cu;
-  if (T_in < 1 || T_in > TACO_MAX_TIN || T_in > TACO_E_SLOTS * n_wg) TACO_FAIL(TACO_EINVAL, "T_in = %d symbols is outside the decoder kernel's capacity 1..%d", T_in, TACO_MAX_TIN);
+  if (T_in < 1 || T_in > TACO_MAX_TIN) TACO_FAIL(TACO_EINVAL, "T_in = %d symbols is outside the decoder kernel's capacity 1..%d", T_in, TACO_MAX_TIN);
   if (max_steps < 1 || max_steps > T_cap) TACO_FAIL(TACO_EINVAL, "max_steps %d outside 1..T_cap=%d", max_steps, T_cap);
 
   DecArgs a;
   a.P = d.P; a.M = d.M; a.Ra = d.R_a; a.Rd = d.R_d; a.A = d.A; a.F = d.F; a.K = d.K; a.n_mel = d.n_mel;
   a.T_in = T_in; a.lens = lens; a.b = b; a.n_wg = n_wg;
-  a.proj_off = 0;   // projection rows on workgroups 0..n_mel; attention positions count down from the last workgroup
   const taco_weights& w = h->w;
   a.prenet_w1 = w.prenet_w1; a.prenet_w2 = w.prenet_w2;
   a.att_w_ih = w.att_w_ih; a.att_w_hh = w.att_w_hh; a.att_b_ih = w.att_b_ih; a.att_b_hh = w.att_b_hh;
-  a.query_w = w.query_w; a.v_w = w.v_w; a.loc_conv_w = w.loc_conv_w; a.loc_dense_w = w.loc_dense_w;
+  a.query_w = w.query_w; a.v_w = w.v_w; a.loc_fold = h->loc_fold;
   a.dec_w_ih = w.dec_w_ih; a.dec_w_hh = w.dec_w_hh; a.dec_b_ih = w.dec_b_ih; a.dec_b_hh = w.dec_b_hh;
   a.proj_w = w.proj_w; a.proj_b = w.proj_b; a.gate_w = w.gate_w; a.gate_b = w.gate_b;
   a.pm = pm; a.G = h->ws_G; a.masks = masks; a.T_cap = T_cap; a.max_steps = max_steps; a.thr = thr;
@@ -682,9 +734,9 @@ int taco_launch_decoder(taco_handle h, const float* memory, const float* pm, int
     std::vector<unsigned long long> st(stamp_count);
     TACO_HIP(hipMemcpy(st.data(), stamps_dev, stamp_count * 8, hipMemcpyDeviceToHost));
     const int nfr = (int)h->dec_ctl_host->n_frames < TACO_STAMP_FRAMES ? (int)h->dec_ctl_host->n_frames : TACO_STAMP_FRAMES;
-    static const char* names[TACO_STAMP_POINTS] = {"frame top done", "S1 publish p1 + attn partial", "gather p1", "S2 + gather p",
-        "S3 attn LSTM", "gather ah", "S4 q + gather q", "S5 energies + gather e", "S6 softmax",
-        "S7 dec LSTM", "proj half + loc features", "gather dh"};
+    static const char* names[TACO_STAMP_POINTS] = {"frame top done", "S1 + S2 (P group)", "gather p", "S3 attn LSTM",
+        "gather ah", "S4 q + energy partials (Q group)", "gather energy partials", "S6 softmax",
+        "S7 dec LSTM", "proj half / location term", "gather dh", "S8 proj (M group)"};
     for (int wg = 0; wg < 2 && nfr > 8; ++wg) {
       double acc[TACO_STAMP_POINTS + 1] = {0};
       int cnt = 0;
@@ -697,7 +749,7 @@ int taco_launch_decoder(taco_handle h, const float* memory, const float* pm, int
       fprintf(stderr, "[taco stamps] workgroup %s, mean over %d frames (us):\n", wg == 0 ? "0" : "200", cnt);
       double tot = 0;
       for (int k = 1; k < TACO_STAMP_POINTS; ++k) { fprintf(stderr, "  %-32s %7.2f\n", names[k], acc[k] / cnt); tot += acc[k] / cnt; }
-      fprintf(stderr, "  %-32s %7.2f\n  total %7.2f\n", "S8 proj + frame top (mel, beats)", acc[TACO_STAMP_POINTS] / cnt, tot + acc[TACO_STAMP_POINTS] / cnt);
+      fprintf(stderr, "  %-32s %7.2f\n  total %7.2f\n", "attn partial + frame top (mel / stop)", acc[TACO_STAMP_POINTS] / cnt, tot + acc[TACO_STAMP_POINTS] / cnt);
     }
   }
 #endif

@@ -122,6 +122,14 @@ __device__ __forceinline__ void taco_publish_rep(taco_granule* base, int cap, in
   for (int r = 0; r < R; ++r) __hip_atomic_store((taco_ggran*)base + (size_t)r * cap + idx, word, TACO_RLX_AGENT);
 }
 
+// The same, spread over the first R lanes of a wave that all hold `value`: one store instruction.
+template <int R>
+__device__ __forceinline__ void taco_publish_lanes(taco_granule* base, int cap, int idx, unsigned epoch, float value,
+                                                   int lane) {
+  const taco_granule word = ((taco_granule)epoch << 32) | (taco_granule)__float_as_uint(value);
+  if (lane < R) __hip_atomic_store((taco_ggran*)base + (size_t)lane * cap + idx, word, TACO_RLX_AGENT);
+}
+
 struct taco_wait_ctx {
   taco_gu32* abort_word;     // global abort flag
   int failed;                // sticky, per thread

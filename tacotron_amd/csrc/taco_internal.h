@@ -33,8 +33,10 @@ constexpr int TACO_MAX_MEL = 80;            // prenet layer 1 is replicated in e
 constexpr int TACO_MAX_TIN = 512;           // symbols per utterance
 constexpr int TACO_DEC_THREADS = 512;       // 8 waves: two LSTM gate rows per wave
 constexpr int TACO_UNITS_PER_WG = 4;        // 4 hidden units x 4 gates = 16 rows per LSTM per workgroup
-constexpr int TACO_E_SLOTS = 2;             // energy positions per workgroup = ceil(T_in / n_wg)
-constexpr int TACO_C_SLOTS = 3;             // context columns per workgroup  = ceil(M / n_wg)
+// Producer groups of the decoder's short vectors (see taco_decoder.hip)
+constexpr int TACO_P_ROWS_WG = 8;           // prenet layer-2 rows per P workgroup (one per wave)
+constexpr int TACO_NQ_WG = 8;               // Q workgroups: attention dimensions are split 8 ways
+constexpr int TACO_MEL_ROWS_WG = 3;         // projection / stop-token rows per M workgroup
 
 // Tagged 8-byte hand-off word: high half = epoch (frame + 1), low half = fp32 payload.
 typedef unsigned long long taco_granule;
@@ -42,12 +44,12 @@ typedef unsigned long long taco_granule;
 // Granule vectors of the decoder, in units of granules from the base; two parities each.  A vector
 // is stored in several identical replicas (producers write all, consumer workgroup j polls replica
 // j % R): 256 pollers on the few cache lines of a short vector is what limits a hand-off's latency.
-constexpr int TACO_REP_SMALL = 8;   // p, q, e, mel, heartbeats (<= 512 granules)
-constexpr int TACO_REP_CTX = 4;     // context (<= 768 granules)
+constexpr int TACO_REP_SMALL = 8;   // prenet output, frame output (<= 256 granules)
+constexpr int TACO_REP_PE = 4;      // energy partial sums (8 groups x positions)
 constexpr int TACO_REP_BIG = 2;     // LSTM hidden states (1024 granules)
 struct taco_dec_layout {
-  int32_t p, ah, q, e, ctx, dh, mel, beat;       // offsets of replica 0
-  int32_t p_cap, ah_cap, q_cap, e_cap, ctx_cap, dh_cap, mel_cap, beat_cap;   // replica strides
+  int32_t p, ah, pe, dh, mel;                    // offsets of replica 0
+  int32_t p_cap, ah_cap, pe_cap, dh_cap, mel_cap;   // replica strides
   int32_t per_parity;                            // granules per parity block
 };
 
@@ -78,6 +80,9 @@ struct taco_handle_s {
   // gate_layer[:, R_d:]  ->  [4*R_a + 4*R_d + n_mel + 1][M]
   float* ctx_w_cat;
   int ctx_rows;
+  // Location layers folded into one filter per attention dimension:
+  // loc_fold[a][c][k] = sum_f location_dense[a][f] * location_conv[f][c][k], rows a >= A zero, [TACO_MAX_A + 4][2][K]
+  float* loc_fold;
   float* ws_G;               // [ctx_rows][T_in] folded context weights G = ctx_w_cat * memory^T
   // workspaces (grow-only)
   float* ws_act[2];          // activation ping-pong [B][C_max][T]
@@ -109,6 +114,7 @@ int taco_launch_enc_lstm(taco_handle h, const float* gx, const int32_t* lens, in
                          hipStream_t s);
 int taco_launch_memory_tail(taco_handle h, const int64_t* speakers, const int32_t* lens, int B, int T,
                             float* memory, float* pm, hipStream_t s);
+int taco_launch_loc_fold(const float* dense_w, const float* conv_w, int A, int F, int K, int rows, float* out, hipStream_t s);
 int taco_launch_slice_cols(const float* src, int ld, int col0, int rows, int cols, float* dst, hipStream_t s);
 int taco_launch_decoder(taco_handle h, const float* memory, const float* pm, int T_in, const int32_t* lens,
                         int b, const uint8_t* masks, int T_cap, int max_steps, float thr, const float* forced_mel,

@@ -311,7 +311,27 @@ __global__ __launch_bounds__(256) void taco_slice_cols_kernel(const float* __res
   }
 }
 
+// Location layers folded: out[a][c][k] = sum_f dense[a][f] * conv[f][c][k]  (rows a >= A are zero).
+// reference: LocationLayer = Conv1d(2 -> F, K, no bias) then Linear(F -> A, no bias), src/tacotron/model.py:20-44.
+__global__ __launch_bounds__(256) void taco_loc_fold_kernel(const float* __restrict__ dense_w, const float* __restrict__ conv_w,
+                                                            int A, int F, int K, int rows, float* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * 2 * K) return;
+  const int a = i / (2 * K), ck = i % (2 * K);
+  float acc = 0.0f;
+  if (a < A)
+    for (int f = 0; f < F; ++f) acc = fmaf(dense_w[(size_t)a * F + f], conv_w[(size_t)f * 2 * K + ck], acc);
+  out[i] = acc;
+}
+
 }  // namespace
+
+int taco_launch_loc_fold(const float* dense_w, const float* conv_w, int A, int F, int K, int rows, float* out, hipStream_t s) {
+  const int n = rows * 2 * K;
+  hipLaunchKernelGGL(taco_loc_fold_kernel, dim3((n + 255) / 256), dim3(256), 0, s, dense_w, conv_w, A, F, K, rows, out);
+  TACO_HIP(hipGetLastError());
+  return TACO_OK;
+}
 
 int taco_launch_slice_cols(const float* src, int ld, int col0, int rows, int cols, float* dst, hipStream_t s) {
   const size_t total = (size_t)rows * cols;

@@ -157,7 +157,8 @@ extern "C" int taco_create(const taco_dims* dims, const taco_weights* weights, i
   const int fold_rows = TACO_MAX_A + 4;                      // a quad of dimensions may reach past A: zero rows
   const size_t n_fold = (size_t)fold_rows * 2 * d.K;
   h->pool_floats = plan.total + n_bn_enc + n_bn_post + (n_wcat + 63) / 64 * 64 + (n_bsum + 63) / 64 * 64 +
-                   (n_ctxw + 63) / 64 * 64 + (n_fold + 63) / 64 * 64;
+                   (n_ctxw + 63) / 64 * 64 + (n_fold + 63) / 64 * 64 + ((size_t)d.P * d.R_d + 63) / 64 * 64 +
+                   ((size_t)d.P + 63) / 64 * 64 + ((size_t)d.n_mel * d.R_d + 63) / 64 * 64;
   if (hipMalloc((void**)&h->pool, h->pool_floats * sizeof(float)) != hipSuccess) {
     delete h;
     TACO_FAIL(TACO_ENOMEM, "hipMalloc of %zu bytes for the weight pool failed", h->pool_floats * sizeof(float));
@@ -211,8 +212,18 @@ extern "C" int taco_create(const taco_dims* dims, const taco_weights* weights, i
   h->loc_fold = cur; cur += (n_fold + 63) / 64 * 64;
   rc = taco_launch_loc_fold(hw.loc_dense_w, hw.loc_conv_w, d.A, d.F, d.K, fold_rows, h->loc_fold, 0);
   if (rc != TACO_OK) { taco_destroy(h); return rc; }
+  {
+    // wf_h = W1 [P][n_mel] * Wp_h [n_mel][R_d] and wf_b = W1 * proj_b, as kernel-size-1 convolutions
+    h->wf_h = cur; cur += ((size_t)d.P * d.R_d + 63) / 64 * 64;
+    h->wf_b = cur; cur += ((size_t)d.P + 63) / 64 * 64;
+    float* wp_h = cur; cur += ((size_t)d.n_mel * d.R_d + 63) / 64 * 64;
+    rc = taco_launch_slice_cols(hw.proj_w, d.R_d + d.M, 0, d.n_mel, d.R_d, wp_h, 0);
+    if (rc == TACO_OK) rc = taco_launch_conv(wp_h, h->wf_h, hw.prenet_w1, nullptr, nullptr, nullptr, nullptr, nullptr, 1, d.n_mel, d.P, 1, d.R_d, 0, 0, 0);
+    if (rc == TACO_OK) rc = taco_launch_conv(hw.proj_b, h->wf_b, hw.prenet_w1, nullptr, nullptr, nullptr, nullptr, nullptr, 1, d.n_mel, d.P, 1, 1, 0, 0, 0);
+    if (rc != TACO_OK) { taco_destroy(h); return rc; }
+  }
   TACO_CREATE_HIP(hipGetLastError());
-  TACO_CREATE_HIP(hipMalloc((void**)&h->ws_G, sizeof(float) * (size_t)h->ctx_rows * TACO_MAX_TIN));
+  TACO_CREATE_HIP(hipMalloc((void**)&h->ws_G, sizeof(float) * (size_t)(h->ctx_rows + d.P) * TACO_MAX_TIN));
 
   // ---- hand-off words, control blocks, events ----
   taco_decoder_fill_layout(&h->dec_lay, h->n_cu);

@@ -21,13 +21,18 @@
 //     multiplies them with the attention weights every workgroup already has after its softmax;
 //   * an all-gather costs the more the more workgroups produce and consume it, so the small matrices
 //     live in three small groups of producer workgroups, and a frame's chain of hand-offs is
-//       decoder hidden (all 256) -> M group (27: projection / stop-token rows, 3 each)
-//       frame output (M)         -> P group (32: prenet layer 1 replicated among them, 8 layer-2 rows each)
+//       decoder hidden (all 256) -> P group (32 workgroups, 8 prenet rows each): layer-1 rows
+//       layer-1 output (P)       -> P group: layer-2 rows
 //       prenet output (P)        -> all: attention LSTM
 //       attention hidden (all)   -> Q group (8: 16 query rows each, the location term and the energy
 //                                   partial sums of their 16 attention dimensions for EVERY position)
 //       energy partials (Q)      -> all: sum of the 8 partials, softmax, decoder LSTM with G * w
-//     five dependent hand-offs per frame, three of them with a small group on one side;
+//     five dependent hand-offs per frame, all but one with a small group on one side; the M group
+//     (27: projection / stop-token rows, 3 each) writes the frame's output beside that chain: only its
+//     stop token is read back (by everyone, at the frame boundary);
+//   * prenet layer 1 never sees a materialised frame: W1 (Wp [dh ; ctx] + b) = (W1 Wp_h) dh + (W1 Gp) w + W1 b,
+//     folded once per model / utterance, so a P wave gets its layer-1 row straight from the decoder
+//     hidden state (teacher forcing applies the plain W1 row to the given frame instead);
 //   * the location layers are folded into one filter per attention dimension, E = dense * conv
 //     (computed once per model), so a Q workgroup needs no intermediate and reads E through scalar loads;
 //   * everything that does not depend on the value being waited for (the recurrent halves of the
@@ -72,19 +77,18 @@ constexpr int L_CELLS = L_RED + 32;                            // LSTM cell stat
 constexpr int L_BIAS = L_CELLS + 8;                            // b_ih + b_hh of my rows [16 + 16]
 constexpr int L_GATE_IN = L_BIAS + 32;                         // stop token of the previous frame [4]
 constexpr int L_ROLE = L_GATE_IN + 4;
-// P group: prenet layer 1 transposed [n_mel][256], its partial sums [8][256], 8 layer-2 rows [256],
-//          decoder input [128], layer-1 output [256], keep bytes [2 parities][2 layers][256 B]
-constexpr int TACO_W1_ROWS = TACO_MAX_MEL;
-constexpr int P1_KPARTS = NW;                                  // layer 1 is split 8 ways over its input columns
-constexpr int P1_KPER = TACO_W1_ROWS / P1_KPARTS;              // 10 input columns per part
-static_assert(P1_KPER * P1_KPARTS == TACO_W1_ROWS && PW == 256, "layer-1 tiling");
-constexpr int LP_W1T = L_ROLE;
-constexpr int LP_P1HALF = LP_W1T + TACO_W1_ROWS * PW;
-constexpr int LP_W2 = LP_P1HALF + P1_KPARTS * PW;
-constexpr int LP_MELIN = LP_W2 + TACO_P_ROWS_WG * PW;
-constexpr int LP_P1 = LP_MELIN + 128;
-constexpr int LP_KEEP = LP_P1 + PW;
+// P group: per wave one row of the prenet: layer 1 folded into the projection [1024 hidden + 512 folded
+//          context] and its bias, the plain layer-1 row [128] (teacher forcing), the layer-2 row [256];
+//          the gathered layer-1 output [256]; keep bytes [2 parities][2 layers][256 B]
+constexpr int PROJ_ROW_LEN = (TACO_ND + NMF) * TACO_CHUNK;
+constexpr int LP_WF = L_ROLE;
+constexpr int LP_W1R = LP_WF + TACO_P_ROWS_WG * PROJ_ROW_LEN;
+constexpr int LP_W2 = LP_W1R + TACO_P_ROWS_WG * 128;
+constexpr int LP_BIAS = LP_W2 + TACO_P_ROWS_WG * PW;
+constexpr int LP_H1 = LP_BIAS + TACO_P_ROWS_WG;
+constexpr int LP_KEEP = LP_H1 + PW;
 constexpr int LP_END = LP_KEEP + 2 * 2 * 64;
+static_assert(TACO_MAX_MEL <= 128 && PW == 256, "prenet row capacities");
 // Q group: 16 query rows [1024], location term + processed memory U[16][positions], v and query
 //          values of my dimensions [16 + 16], energy partials per quad of dimensions [4][positions],
 //          the folded location filter of my dimensions
@@ -98,7 +102,6 @@ constexpr int LOC_KSTEPS = (2 * TACO_MAX_K + 3) / 4;           // 16 steps of 4 
 static_assert(QD == 16 && LOC_KSTEPS == 16, "the location term is a 16 x 16 x (16 x 4) matrix-core product per 16 positions");
 constexpr int LQ_END = LQ_E + LOC_KSTEPS * 64;
 // M group: 3 projection rows [1024 hidden + 512 folded context], their biases [4]
-constexpr int PROJ_ROW_LEN = (TACO_ND + NMF) * TACO_CHUNK;
 constexpr int LM_ROWS = L_ROLE;
 constexpr int LM_BIAS = LM_ROWS + TACO_MEL_ROWS_WG * PROJ_ROW_LEN;
 constexpr int LM_END = LM_BIAS + 4;
@@ -110,7 +113,7 @@ struct DecArgs {
   int P, M, Ra, Rd, A, F, K, n_mel, T_in, n_wg;
   const int32_t* lens;   // device, or NULL = T_in symbols
   int b;                 // utterance index into lens
-  const float *prenet_w1, *prenet_w2, *att_w_ih, *att_w_hh, *att_b_ih, *att_b_hh, *query_w, *v_w, *loc_fold,
+  const float *prenet_w1, *prenet_w2, *wf_h, *wf_b, *att_w_ih, *att_w_hh, *att_b_ih, *att_b_hh, *query_w, *v_w, *loc_fold,
       *dec_w_ih, *dec_w_hh, *dec_b_ih, *dec_b_hh, *proj_w, *proj_b, *gate_w, *gate_b;
   const float* pm;
   const float* G;        // folded context weights [4*Ra + 4*Rd + n_mel + 1][T_in], zero at positions >= len
@@ -306,13 +309,14 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
   const bool own_m = m_row <= NMEL;
   float* my_proj = lds + LM_ROWS + (wave - 1) * PROJ_ROW_LEN;                        // valid for own_m waves
   const int n_hc = Rd + M;
-  if (is_p) {
-    _Pragma("unroll 1") for (int k = tid; k < P * NMEL; k += NT) {
-      const int r = k / NMEL, c = k % NMEL;
-      lds[LP_W1T + c * PW + r] = a.prenet_w1[k];
-    }
-    if (own_p)
-      _Pragma("unroll 1") for (int k = lane; k < P; k += 64) lds[LP_W2 + wave * PW + k] = a.prenet_w2[(size_t)p_row * P + k];
+  float* my_wf = lds + LP_WF + wave * PROJ_ROW_LEN;                                  // valid for own_p waves
+  if (own_p) {
+    const float* G_pre = G_proj + (size_t)(NMEL + 1) * a.T_in;                       // layer 1 x projection's folded context rows
+    _Pragma("unroll 1") for (int k = lane; k < Rd; k += 64) my_wf[k] = a.wf_h[(size_t)p_row * Rd + k];
+    _Pragma("unroll 1") for (int k = lane; k < a.T_in; k += 64) my_wf[TACO_ND * TACO_CHUNK + k] = G_pre[(size_t)p_row * a.T_in + k];
+    _Pragma("unroll 1") for (int k = lane; k < NMEL; k += 64) lds[LP_W1R + wave * 128 + k] = a.prenet_w1[(size_t)p_row * NMEL + k];
+    _Pragma("unroll 1") for (int k = lane; k < P; k += 64) lds[LP_W2 + wave * PW + k] = a.prenet_w2[(size_t)p_row * P + k];
+    if (lane == 0) lds[LP_BIAS + wave] = a.wf_b[p_row];
   }
   if (is_q) {
     _Pragma("unroll 1") for (int k = tid; k < q_cnt * Ra; k += NT) {
@@ -386,22 +390,12 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
   if (is_q) update_location_term();
   __syncthreads();
   for (;; ++t) {
-    // ============ frame boundary: the previous frame's output (P group) / its stop token (everyone) ============
+    // ============ frame boundary: the previous frame's stop token ============
     if (t > 0) {
       const taco_granule* gp = a.gran + (size_t)((t - 1) & 1) * a.lay.per_parity;
       const unsigned ep_prev = (unsigned)t;
       const taco_granule* melv = gp + a.lay.mel + (j % TACO_REP_SMALL) * a.lay.mel_cap;
-      if (is_p) {
-        if (tid <= NMEL) {
-          const float v = taco_wait_one(melv, tid, ep_prev, wctx, 0x100u);
-          if (tid == NMEL) lds[L_GATE_IN] = v;
-          else if (!forced) lds[LP_MELIN + tid] = v;
-        }
-        if (forced && tid < NMEL) lds[LP_MELIN + tid] = a.forced_mel[(size_t)tid * a.T_cap + (t - 1)];
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the keep-byte DMA issued last frame has landed
-      } else if (tid == 0) {
-        lds[L_GATE_IN] = taco_wait_one(melv, NMEL, ep_prev, wctx, 0x100u);
-      }
+      if (tid == 0) lds[L_GATE_IN] = taco_wait_one(melv, NMEL, ep_prev, wctx, 0x100u);
       if (__syncthreads_or(wctx.failed)) break;
       if (!forced && taco_sigmoid(lds[L_GATE_IN]) > a.thr) { stopped = 1; break; }
     }
@@ -413,7 +407,6 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
     const unsigned ep = (unsigned)t + 1u;
     taco_granule* g = a.gran + (size_t)(t & 1) * a.lay.per_parity;
     if (is_p) {
-      // keep-bits of the two prenet dropouts: layer 1 for the row this thread finishes, layer 2 for my rows
       const unsigned char* keep_now = keep_lds + (t & 1) * 512;
       if (wave == NW - 1 && t + 1 < a.max_steps && lane * 4 < P) {
         // next frame's keep bytes, fetched a frame ahead (a first-touch line comes from HBM)
@@ -424,36 +417,11 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 4, 0, 0);
         __builtin_amdgcn_global_load_lds((gptr_t)(src + P), (lptr_t)(dst + 64), 4, 0, 0);
       }
-      // ---- S1: prenet layer 1, ALL rows, in every P workgroup (20 k MACs buy one hand-off) ----
-      // thread = (4 adjacent rows, one of 8 slices of the input columns); rows beyond P, columns beyond
-      // n_mel are zero in LDS
-      {
-        const int rq = lane, kp = wave;
-        float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-#pragma unroll 5
-        for (int i = 0; i < P1_KPER; ++i) {
-          const int k = kp * P1_KPER + i;
-          const float4 wv = *reinterpret_cast<const float4*>(lds + LP_W1T + k * PW + rq * 4);
-          const float x = lds[LP_MELIN + k];
-          acc.x = fmaf(wv.x, x, acc.x);
-          acc.y = fmaf(wv.y, x, acc.y);
-          acc.z = fmaf(wv.z, x, acc.z);
-          acc.w = fmaf(wv.w, x, acc.w);
-        }
-        *reinterpret_cast<float4*>(lds + LP_P1HALF + kp * PW + rq * 4) = acc;
-      }
-      taco_lds_barrier();
-      if (tid < PW) {
-        float v = 0.0f;
-#pragma unroll
-        for (int i = 0; i < P1_KPARTS; ++i) v += lds[LP_P1HALF + i * PW + tid];
-        v = v > 0.0f ? v : 0.0f;
-        lds[LP_P1 + tid] = keep_now[tid] ? v * 2.0f : 0.0f;
-      }
-      taco_lds_barrier();
-      // ---- S2: prenet layer 2, one row per wave ----
+      // ---- prenet layer 2, one row per wave, on the layer-1 output the P group exchanged (all zero for
+      //      frame 0: the go frame is zero and the layers have no bias) ----
+      if (t > 0) taco_gather<NT>(g + a.lay.h1 + (j % TACO_REP_SMALL) * a.lay.h1_cap, P, ep, lds + LP_H1, wctx, 0x300u);
       if (own_p) {
-        float v = taco_wave_sum(row_partial<TACO_NP>(lds + LP_W2 + wave * PW, lds + LP_P1, lane));
+        float v = taco_wave_sum(row_partial<TACO_NP>(lds + LP_W2 + wave * PW, lds + LP_H1, lane));
         v = v > 0.0f ? v : 0.0f;
         v = keep_now[256 + p_row] ? v * 2.0f : 0.0f;
         taco_publish_lanes<TACO_REP_SMALL>(g + a.lay.p, a.lay.p_cap, p_row, ep, v, lane);
@@ -599,17 +567,40 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
     if (own_m) acc_p = row_partial<NMF>(my_proj + TACO_ND * TACO_CHUNK, aw, lane);
     TACO_STAMP(9);
 
-    // ============ S8: mel / stop-token projection rows (M group) ============
+    // ============ S8: mel / stop-token projection rows (M group), next frame's prenet layer 1 (P group) ============
+    if (is_p) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // next frame's keep bytes (LDS-DMA) have landed
     taco_gather<NT>(g + a.lay.dh + (j % TACO_REP_BIG) * a.lay.dh_cap, Rd, ep, lds + L_XDH, wctx, 0x900u);
     TACO_STAMP(10);
     if (own_m) {
       acc_p += row_partial<TACO_ND>(my_proj, lds + L_XDH, lane);
       const float v = taco_wave_sum(acc_p) + lds[LM_BIAS + wave];
-      taco_publish_lanes<TACO_REP_SMALL>(g + a.lay.mel, a.lay.mel_cap, m_row, ep, v, lane);
+      if (m_row == NMEL) taco_publish_lanes<TACO_REP_SMALL>(g + a.lay.mel, a.lay.mel_cap, m_row, ep, v, lane);
       if (lane == 0) {
         if (m_row < NMEL) a.mel[(size_t)m_row * a.T_cap + t] = v;
         else a.gate[t] = v;
       }
+    }
+    // P group: the next frame's prenet layer-1 rows.  Free running, layer 1 is applied to this frame's
+    // output without materialising it: W1 (Wp [dh ; ctx] + b) = (W1 Wp_h) dh + (W1 Gp) w + W1 b, one
+    // folded row per wave.  Teacher forcing applies the plain layer-1 row to the given frame.
+    if (own_p && t + 1 < a.max_steps) {
+      float x1;
+      if (forced) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int k = lane + 64 * i;
+          if (k < NMEL) acc = fmaf(lds[LP_W1R + wave * 128 + k], a.forced_mel[(size_t)k * a.T_cap + t], acc);
+        }
+        x1 = taco_wave_sum(acc);
+      } else {
+        x1 = taco_wave_sum(row_partial<TACO_ND>(my_wf, lds + L_XDH, lane) + row_partial<NMF>(my_wf + TACO_ND * TACO_CHUNK, aw, lane)) +
+             lds[LP_BIAS + wave];
+      }
+      x1 = x1 > 0.0f ? x1 : 0.0f;
+      x1 = keep_lds[((t + 1) & 1) * 512 + p_row] ? x1 * 2.0f : 0.0f;
+      taco_granule* gn = a.gran + (size_t)((t + 1) & 1) * a.lay.per_parity;
+      taco_publish_lanes<TACO_REP_SMALL>(gn + a.lay.h1, a.lay.h1_cap, p_row, ep + 1u, x1, lane);
     }
     TACO_STAMP(11);
     // while the frame output travels: next frame's attention-LSTM partial sums over
@@ -641,6 +632,7 @@ static void fill_layout(taco_dec_layout& lay, int n_wg) {
     off += cap * reps;
     return at;
   };
+  lay.h1 = take(TACO_NP * TACO_CHUNK, TACO_REP_SMALL, lay.h1_cap);
   lay.p = take(TACO_NP * TACO_CHUNK, TACO_REP_SMALL, lay.p_cap);
   lay.ah = take(TACO_NA * TACO_CHUNK, TACO_REP_BIG, lay.ah_cap);
   lay.pe = take(TACO_NQ_WG * TACO_MAX_TIN, TACO_REP_PE, lay.pe_cap);
@@ -685,7 +677,7 @@ int taco_launch_decoder(taco_handle h, const float* memory, const float* pm, int
   a.P = d.P; a.M = d.M; a.Ra = d.R_a; a.Rd = d.R_d; a.A = d.A; a.F = d.F; a.K = d.K; a.n_mel = d.n_mel;
   a.T_in = T_in; a.lens = lens; a.b = b; a.n_wg = n_wg;
   const taco_weights& w = h->w;
-  a.prenet_w1 = w.prenet_w1; a.prenet_w2 = w.prenet_w2;
+  a.prenet_w1 = w.prenet_w1; a.prenet_w2 = w.prenet_w2; a.wf_h = h->wf_h; a.wf_b = h->wf_b;
   a.att_w_ih = w.att_w_ih; a.att_w_hh = w.att_w_hh; a.att_b_ih = w.att_b_ih; a.att_b_hh = w.att_b_hh;
   a.query_w = w.query_w; a.v_w = w.v_w; a.loc_fold = h->loc_fold;
   a.dec_w_ih = w.dec_w_ih; a.dec_w_hh = w.dec_w_hh; a.dec_b_ih = w.dec_b_ih; a.dec_b_hh = w.dec_b_hh;
@@ -699,6 +691,13 @@ int taco_launch_decoder(taco_handle h, const float* memory, const float* pm, int
   const int rc = taco_launch_conv(memory, h->ws_G, h->ctx_w_cat, nullptr, nullptr, nullptr, nullptr,
                                   lens ? lens + b : nullptr, 1, d.M, h->ctx_rows, 1, T_in, 0, /*in_time_major*/ 1, s);
   if (rc != TACO_OK) return rc;
+  // ... and prenet layer 1 applied to the projection's folded rows: [P][T_in] = W1 [P][n_mel] * G_proj [n_mel][T_in]
+  {
+    float* g_proj = h->ws_G + (size_t)(4 * d.R_a + 4 * d.R_d) * T_in;
+    const int rc2 = taco_launch_conv(g_proj, h->ws_G + (size_t)h->ctx_rows * T_in, h->w.prenet_w1, nullptr, nullptr, nullptr,
+                                     nullptr, lens ? lens + b : nullptr, 1, d.n_mel, d.P, 1, T_in, 0, 0, s);
+    if (rc2 != TACO_OK) return rc2;
+  }
 
   const size_t gran_bytes = (size_t)h->dec_lay.per_parity * 2 * sizeof(taco_granule);
   TACO_HIP(hipMemsetAsync(h->dec_gran, 0, gran_bytes, s));

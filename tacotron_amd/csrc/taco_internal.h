@@ -48,8 +48,8 @@ constexpr int TACO_REP_SMALL = 8;   // prenet output, frame output (<= 256 granu
 constexpr int TACO_REP_PE = 4;      // energy partial sums (8 groups x positions)
 constexpr int TACO_REP_BIG = 2;     // LSTM hidden states (1024 granules)
 struct taco_dec_layout {
-  int32_t p, ah, pe, dh, mel;                    // offsets of replica 0
-  int32_t p_cap, ah_cap, pe_cap, dh_cap, mel_cap;   // replica strides
+  int32_t h1, p, ah, pe, dh, mel;                // offsets of replica 0
+  int32_t h1_cap, p_cap, ah_cap, pe_cap, dh_cap, mel_cap;   // replica strides
   int32_t per_parity;                            // granules per parity block
 };
 
@@ -83,6 +83,9 @@ struct taco_handle_s {
   // Location layers folded into one filter per attention dimension:
   // loc_fold[a][c][k] = sum_f location_dense[a][f] * location_conv[f][c][k], rows a >= A zero, [TACO_MAX_A + 4][2][K]
   float* loc_fold;
+  // Prenet layer 1 folded into the mel projection: wf_h [P][R_d] = W1 * linear_projection[:, :R_d], wf_b [P] = W1 * bias
+  float* wf_h;
+  float* wf_b;
   float* ws_G;               // [ctx_rows][T_in] folded context weights G = ctx_w_cat * memory^T
   // workspaces (grow-only)
   float* ws_act[2];          // activation ping-pong [B][C_max][T]

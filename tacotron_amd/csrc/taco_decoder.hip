@@ -56,8 +56,8 @@ constexpr int NW = NT / 64;                          // waves per workgroup
 // input position: NMF chunks cover TACO_MAX_TIN positions.
 constexpr int NMF = 2;
 static_assert(NMF * TACO_CHUNK == TACO_MAX_TIN, "folded context chunks must cover the position capacity");
-constexpr int CH_A = TACO_NP + NMF + TACO_NA;       // 7 chunks per attention-LSTM row
-constexpr int CH_D = TACO_NA + NMF + TACO_ND;       // 10 chunks per decoder-LSTM row
+// A kernel instance holds NCTX <= NMF of them in registers: utterances of up to 256 positions run the
+// instance with one chunk, which leaves 16 registers per lane to the rest of the frame.
 constexpr int HALO = 16;                            // >= (K-1)/2 zero columns around the weights
 constexpr int PW = TACO_NP * TACO_CHUNK;            // prenet width capacity (256)
 constexpr int QD = TACO_MAX_A / TACO_NQ_WG;         // attention dimensions per Q workgroup (16)
@@ -90,14 +90,17 @@ constexpr int LP_KEEP = LP_H1 + PW;
 constexpr int LP_END = LP_KEEP + 2 * 2 * 64;
 static_assert(TACO_MAX_MEL <= 128 && PW == 256, "prenet row capacities");
 // Q group: 16 query rows [1024], location term + processed memory U[16][positions], v and query
-//          values of my dimensions [16 + 16], energy partials per quad of dimensions [4][positions],
+//          of my dimensions [16], processed memory of my dimensions [16][256],
 //          the folded location filter of my dimensions
 constexpr int LQ_ROWS = L_ROLE;
 constexpr int LQ_U = LQ_ROWS + QD * TACO_NA * TACO_CHUNK;
 constexpr int LQ_V = LQ_U + QD * TACO_MAX_TIN;
-constexpr int LQ_Q = LQ_V + QD;
-constexpr int LQ_PE4 = LQ_Q + QD;
-constexpr int LQ_E = LQ_PE4 + (QD / 4) * TACO_MAX_TIN;        // folded location filter as MFMA A operands [16 k-steps][64 lanes]
+constexpr int LQ_PE8 = L_PE;                                   // per-wave energy partials live where the gathered partials
+                                                                // will land (dead until then; a barrier separates the uses)
+static_assert(NW <= TACO_NQ_WG, "per-wave partials fit the gathered-partials area");
+constexpr int LQ_PM_POS = 256;                                 // processed memory of my dimensions is kept in LDS for
+constexpr int LQ_PM = LQ_V + QD;                               // utterances up to this many positions [16][256]
+constexpr int LQ_E = LQ_PM + QD * LQ_PM_POS;        // folded location filter as MFMA A operands [16 k-steps][64 lanes]
 constexpr int LOC_KSTEPS = (2 * TACO_MAX_K + 3) / 4;           // 16 steps of 4 taps cover 2 x 31
 static_assert(QD == 16 && LOC_KSTEPS == 16, "the location term is a 16 x 16 x (16 x 4) matrix-core product per 16 positions");
 constexpr int LQ_END = LQ_E + LOC_KSTEPS * 64;
@@ -126,7 +129,7 @@ struct DecArgs {
   taco_dec_layout lay;
   taco_dec_ctl* ctl;
 #ifdef TACO_STAMPS
-  unsigned long long* stamps;   // diagnostic build only: [2 workgroups][TACO_STAMP_FRAMES][TACO_STAMP_POINTS]
+  unsigned long long* stamps;   // diagnostic build only: [3 workgroups][TACO_STAMP_FRAMES][TACO_STAMP_POINTS]
 #endif
 };
 
@@ -134,8 +137,8 @@ struct DecArgs {
 constexpr int TACO_STAMP_FRAMES = 256, TACO_STAMP_POINTS = 12;
 #define TACO_STAMP(k)                                                                                   \
   do {                                                                                                  \
-    if (tid == 0 && (j == 0 || j == 200) && t < TACO_STAMP_FRAMES)                                      \
-      a.stamps[((size_t)(j == 0 ? 0 : 1) * TACO_STAMP_FRAMES + t) * TACO_STAMP_POINTS + (k)] = wall_clock64(); \
+    if (tid == 0 && (j == 0 || j == 32 || j == 200) && t < TACO_STAMP_FRAMES)                           \
+      a.stamps[((size_t)(j == 0 ? 0 : j == 32 ? 1 : 2) * TACO_STAMP_FRAMES + t) * TACO_STAMP_POINTS + (k)] = wall_clock64(); \
   } while (0)
 #else
 #define TACO_STAMP(k) do {} while (0)
@@ -205,8 +208,10 @@ __device__ __forceinline__ float lstm_cell_lanes(const float* gates_lds, const f
 // STD = true fixes the extents of the usual checkpoint geometry (prenet 256, both LSTMs 1024, attention
 // 128 / kernel 31, 80 mel channels, 256 workgroups) at compile time: fewer live scalars and no bounds
 // arithmetic in the frame loop.  STD = false takes every extent from the arguments.
-template <bool STD>
+template <bool STD, int NCTX>
 __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const DecArgs a) {
+  constexpr int CH_A = TACO_NP + NCTX + TACO_NA;    // chunks per attention-LSTM row (6 or 7)
+  constexpr int CH_D = TACO_NA + NCTX + TACO_ND;    // chunks per decoder-LSTM row (9 or 10)
   const int P = STD ? 256 : a.P;
   const int Ra = STD ? 1024 : a.Ra;
   const int Rd = STD ? 1024 : a.Rd;
@@ -253,11 +258,11 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
             if (c < TACO_NP) {
               const int col = c * TACO_CHUNK + lane * 4 + e;
               if (col < P) v = a.att_w_ih[(size_t)ra * n_ih_a + col];
-            } else if (c < TACO_NP + NMF) {
+            } else if (c < TACO_NP + NCTX) {
               const int col = (c - TACO_NP) * TACO_CHUNK + lane * 4 + e;
               if (col < a.T_in) v = G_att[(size_t)ra * a.T_in + col];
             } else {
-              const int col = (c - TACO_NP - NMF) * TACO_CHUNK + lane * 4 + e;
+              const int col = (c - TACO_NP - NCTX) * TACO_CHUNK + lane * 4 + e;
               if (col < Ra) v = a.att_w_hh[(size_t)ra * Ra + col];
             }
           }
@@ -274,11 +279,11 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
             if (c < TACO_NA) {
               const int col = c * TACO_CHUNK + lane * 4 + e;
               if (col < Ra) v = a.dec_w_ih[(size_t)rd * n_ih_d + col];
-            } else if (c < TACO_NA + NMF) {
+            } else if (c < TACO_NA + NCTX) {
               const int col = (c - TACO_NA) * TACO_CHUNK + lane * 4 + e;
               if (col < a.T_in) v = G_dec[(size_t)rd * a.T_in + col];
             } else {
-              const int col = (c - TACO_NA - NMF) * TACO_CHUNK + lane * 4 + e;
+              const int col = (c - TACO_NA - NCTX) * TACO_CHUNK + lane * 4 + e;
               if (col < Rd) v = a.dec_w_hh[(size_t)rd * Rd + col];
             }
           }
@@ -324,6 +329,11 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
       lds[LQ_ROWS + r * (TACO_NA * TACO_CHUNK) + c] = a.query_w[(size_t)(q_base + r) * Ra + c];
     }
     if (tid < q_cnt) lds[LQ_V + tid] = a.v_w[q_base + tid];
+    if (len <= LQ_PM_POS)
+      _Pragma("unroll 1") for (int k = tid; k < q_cnt * len; k += NT) {
+        const int d = k % q_cnt, sp = k / q_cnt;
+        lds[LQ_PM + d * LQ_PM_POS + sp] = a.pm[(size_t)sp * A + q_base + d];
+      }
   }
   if (own_m) {
     const float* src = m_row < NMEL ? a.proj_w + (size_t)m_row * n_hc : a.gate_w;
@@ -356,8 +366,6 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
   // B[k = l>>4][col l&15]; the result holds column l&15, rows 4*(l>>4) + r in register r).  A wave takes
   // every 8th tile.  With all-zero attention weights (before frame 0) U = processed memory.
   typedef float taco_f32x4 __attribute__((ext_vector_type(4)));
-  const int quad = wave >> 1;                    // energy partials: 4 quads of dimensions x 2 waves each
-  const int sl = tid & 127;
   if (is_q) {
     _Pragma("unroll 1") for (int i = tid; i < LOC_KSTEPS * 64; i += NT) {
       const int m = i >> 6, l = i & 63;
@@ -368,6 +376,7 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
   auto update_location_term = [&]() {
     const int col = lane & 15, kq = lane >> 4;
     _Pragma("unroll 1") for (int s0 = wave * 16; s0 < len; s0 += NW * 16) {
+      const int s = s0 + col;
       taco_f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll 2
       for (int m = 0; m < LOC_KSTEPS; ++m) {
@@ -377,11 +386,12 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
         const float xv = lds[(c ? L_CUM : L_AW) + HALO + s0 + col + (ck - c * K) - pad];
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[LQ_E + m * 64 + lane], xv, acc, 0, 0, 0);
       }
-      const int s = s0 + col;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int d = 4 * kq + r;
-        const float pmv = (s < len && d < q_cnt) ? a.pm[(size_t)s * A + q_base + d] : 0.0f;
+        float pmv;                                 // processed memory: LDS copy if the utterance fits, else global
+        if (len <= LQ_PM_POS) pmv = lds[LQ_PM + d * LQ_PM_POS + s0 + col];
+        else pmv = (s < len && d < q_cnt) ? a.pm[(size_t)s * A + q_base + d] : 0.0f;
         lds[LQ_U + d * TACO_MAX_TIN + s] = acc[r] + pmv;
       }
     }
@@ -395,7 +405,10 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
       const taco_granule* gp = a.gran + (size_t)((t - 1) & 1) * a.lay.per_parity;
       const unsigned ep_prev = (unsigned)t;
       const taco_granule* melv = gp + a.lay.mel + (j % TACO_REP_SMALL) * a.lay.mel_cap;
-      if (tid == 0) lds[L_GATE_IN] = taco_wait_one(melv, NMEL, ep_prev, wctx, 0x100u);
+      // One thread fetches the stop token.  (The P group deliberately does not poll for its layer-1 vector
+      // here as well, although both were published together: 32 x 256 early pollers on those lines delay
+      // the stores they are waiting for by more than the second round trip costs.)
+      if (tid == NT - 1) lds[L_GATE_IN] = taco_wait_one(melv, NMEL, ep_prev, wctx, 0x100u);
       if (__syncthreads_or(wctx.failed)) break;
       if (!forced && taco_sigmoid(lds[L_GATE_IN]) > a.thr) { stopped = 1; break; }
     }
@@ -450,44 +463,37 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
     TACO_STAMP(3);
     // meanwhile: decoder-LSTM partial over the previous decoder hidden state
     float acc_d[2] = {0.0f, 0.0f};
-    if (act_d) dot_chunks<TACO_ND>(wd[0] + TACO_NA + NMF, wd[1] + TACO_NA + NMF, lds + L_XDH, lane, acc_d);
+    if (act_d) dot_chunks<TACO_ND>(wd[0] + TACO_NA + NCTX, wd[1] + TACO_NA + NCTX, lds + L_XDH, lane, acc_d);
 
     // ============ S4: query rows and energy partial sums (Q group) ============
     taco_gather<NT>(g + a.lay.ah + (j % TACO_REP_BIG) * a.lay.ah_cap, Ra, ep, lds + L_XAH, wctx, 0x500u);
     TACO_STAMP(4);
     if (is_q) {
+      // wave w: query values of dimensions 2w, 2w+1, then their energy terms for every position (lane =
+      // position); the 8 waves' partial sums meet in LDS
+      float qv[2], vv[2];
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         const int row = wave * 2 + r;
-        if (row < q_cnt) {
-          const float v = taco_wave_sum(row_partial<TACO_NA>(lds + LQ_ROWS + row * (TACO_NA * TACO_CHUNK), lds + L_XAH, lane));
-          if (lane == 0) lds[LQ_Q + row] = v;
-        }
+        qv[r] = taco_wave_sum(row_partial<TACO_NA>(lds + LQ_ROWS + row * (TACO_NA * TACO_CHUNK), lds + L_XAH, lane));
+        vv[r] = lds[LQ_V + row];            // rows beyond my dimensions: zero row, v = 0, finite U
       }
-      taco_lds_barrier();
-      // thread = (position, quad of dimensions): sum over the quad of v * tanh(q + location + processed memory)
-      if (quad * 4 < q_cnt) {
-        _Pragma("unroll 1") for (int s = sl; s < len; s += 128) {
-          float acc = 0.0f;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int d = quad * 4 + i;      // rows beyond my dimensions have v = 0 and finite U
-            acc = fmaf(lds[LQ_V + d], taco_tanh(lds[LQ_Q + d] + lds[LQ_U + d * TACO_MAX_TIN + s]), acc);
-          }
-          lds[LQ_PE4 + quad * TACO_MAX_TIN + s] = acc;
-        }
+      _Pragma("unroll 2") for (int s = lane; s < len; s += 64) {
+        const float e0 = vv[0] * taco_tanh(qv[0] + lds[LQ_U + (wave * 2 + 0) * TACO_MAX_TIN + s]);
+        const float e1 = vv[1] * taco_tanh(qv[1] + lds[LQ_U + (wave * 2 + 1) * TACO_MAX_TIN + s]);
+        lds[LQ_PE8 + wave * TACO_MAX_TIN + s] = e0 + e1;
       }
       taco_lds_barrier();
       {
-        const int nquad = (q_cnt + 3) / 4;
         const int grp = j - q_off;
-        _Pragma("unroll 1") for (int it = tid; it < len * TACO_REP_PE; it += NT) {
-          const int s = it % len, rep = it / len;
-          float e = lds[LQ_PE4 + s];
-          for (int qq = 1; qq < nquad; ++qq) e += lds[LQ_PE4 + qq * TACO_MAX_TIN + s];
-          taco_publish(g + a.lay.pe + (size_t)rep * a.lay.pe_cap, grp * len + s, ep, e);
+        _Pragma("unroll 1") for (int s = tid; s < len; s += NT) {
+          float e = 0.0f;
+#pragma unroll
+          for (int w8 = 0; w8 < NW; ++w8) e += lds[LQ_PE8 + w8 * TACO_MAX_TIN + s];
+          taco_publish_rep<TACO_REP_PE>(g + a.lay.pe, a.lay.pe_cap, grp * len + s, ep, e);
         }
       }
+      taco_lds_barrier();                          // the per-wave partials' area is about to receive the gathered ones
     }
     if (act_d) dot_chunks<TACO_NA>(wd[0], wd[1], lds + L_XAH, lane, acc_d);
     TACO_STAMP(5);
@@ -547,7 +553,7 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
     const float* aw = lds + L_AW + HALO;          // this frame's attention weights, zero beyond len
     if (act_d) {
       dot_chunks<1>(wd[0] + TACO_NA, wd[1] + TACO_NA, aw, lane, acc_d);
-      if (len > TACO_CHUNK) dot_chunks<1>(wd[0] + TACO_NA + 1, wd[1] + TACO_NA + 1, aw + TACO_CHUNK, lane, acc_d);
+      if (NCTX > 1) dot_chunks<1>(wd[0] + TACO_NA + NCTX - 1, wd[1] + TACO_NA + NCTX - 1, aw + TACO_CHUNK, lane, acc_d);
       const float s0 = taco_wave_sum(acc_d[0]);
       const float s1 = taco_wave_sum(acc_d[1]);
       if (lane == 0) {
@@ -564,7 +570,7 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
     TACO_STAMP(8);
     // meanwhile: folded-context half of my projection rows (M group)
     float acc_p = 0.0f;
-    if (own_m) acc_p = row_partial<NMF>(my_proj + TACO_ND * TACO_CHUNK, aw, lane);
+    if (own_m) acc_p = row_partial<NCTX>(my_proj + TACO_ND * TACO_CHUNK, aw, lane);
     TACO_STAMP(9);
 
     // ============ S8: mel / stop-token projection rows (M group), next frame's prenet layer 1 (P group) ============
@@ -594,7 +600,7 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
         }
         x1 = taco_wave_sum(acc);
       } else {
-        x1 = taco_wave_sum(row_partial<TACO_ND>(my_wf, lds + L_XDH, lane) + row_partial<NMF>(my_wf + TACO_ND * TACO_CHUNK, aw, lane)) +
+        x1 = taco_wave_sum(row_partial<TACO_ND>(my_wf, lds + L_XDH, lane) + row_partial<NCTX>(my_wf + TACO_ND * TACO_CHUNK, aw, lane)) +
              lds[LP_BIAS + wave];
       }
       x1 = x1 > 0.0f ? x1 : 0.0f;
@@ -609,8 +615,8 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
     acc_a[1] = 0.0f;
     if (act_a) {
       dot_chunks<1>(wa[0] + TACO_NP, wa[1] + TACO_NP, aw, lane, acc_a);
-      if (len > TACO_CHUNK) dot_chunks<1>(wa[0] + TACO_NP + 1, wa[1] + TACO_NP + 1, aw + TACO_CHUNK, lane, acc_a);
-      dot_chunks<TACO_NA>(wa[0] + TACO_NP + NMF, wa[1] + TACO_NP + NMF, lds + L_XAH, lane, acc_a);
+      if (NCTX > 1) dot_chunks<1>(wa[0] + TACO_NP + NCTX - 1, wa[1] + TACO_NP + NCTX - 1, aw + TACO_CHUNK, lane, acc_a);
+      dot_chunks<TACO_NA>(wa[0] + TACO_NP + NCTX, wa[1] + TACO_NP + NCTX, lds + L_XAH, lane, acc_a);
     }
   }
 
@@ -708,7 +714,7 @@ int taco_launch_decoder(taco_handle h, const float* memory, const float* pm, int
 
 #ifdef TACO_STAMPS
   static unsigned long long* stamps_dev = nullptr;
-  const size_t stamp_count = (size_t)2 * TACO_STAMP_FRAMES * TACO_STAMP_POINTS;
+  const size_t stamp_count = (size_t)3 * TACO_STAMP_FRAMES * TACO_STAMP_POINTS;
   if (!stamps_dev) TACO_HIP(hipMalloc((void**)&stamps_dev, stamp_count * 8));
   TACO_HIP(hipMemsetAsync(stamps_dev, 0, stamp_count * 8, s));
   a.stamps = stamps_dev;
@@ -716,8 +722,10 @@ int taco_launch_decoder(taco_handle h, const float* memory, const float* pm, int
   TACO_HIP(hipEventRecord(h->ev_start, s));
   const bool std_geom = d.P == 256 && d.R_a == 1024 && d.R_d == 1024 && d.A == 128 && d.F == 32 && d.K == 31 &&
                         d.n_mel == 80 && n_wg == 256;
-  if (std_geom) hipLaunchKernelGGL(taco_decoder_kernel<true>, dim3(n_wg), dim3(NT), taco_decoder_lds_bytes(), s, a);
-  else hipLaunchKernelGGL(taco_decoder_kernel<false>, dim3(n_wg), dim3(NT), taco_decoder_lds_bytes(), s, a);
+  const bool one_chunk = T_in <= TACO_CHUNK;     // all positions fit the first folded-context chunk
+  auto kern = std_geom ? (one_chunk ? taco_decoder_kernel<true, 1> : taco_decoder_kernel<true, 2>)
+                       : (one_chunk ? taco_decoder_kernel<false, 1> : taco_decoder_kernel<false, 2>);
+  hipLaunchKernelGGL(kern, dim3(n_wg), dim3(NT), taco_decoder_lds_bytes(), s, a);
   TACO_HIP(hipGetLastError());
   TACO_HIP(hipEventRecord(h->ev_stop, s));
   h->timing_valid = 1;
@@ -736,7 +744,7 @@ int taco_launch_decoder(taco_handle h, const float* memory, const float* pm, int
     static const char* names[TACO_STAMP_POINTS] = {"frame top done", "S1 + S2 (P group)", "gather p", "S3 attn LSTM",
         "gather ah", "S4 q + energy partials (Q group)", "gather energy partials", "S6 softmax",
         "S7 dec LSTM", "proj half / location term", "gather dh", "S8 proj (M group)"};
-    for (int wg = 0; wg < 2 && nfr > 8; ++wg) {
+    for (int wg = 0; wg < 3 && nfr > 8; ++wg) {
       double acc[TACO_STAMP_POINTS + 1] = {0};
       int cnt = 0;
       for (int t = 4; t + 1 < nfr; ++t, ++cnt) {
@@ -745,7 +753,7 @@ int taco_launch_decoder(taco_handle h, const float* memory, const float* pm, int
         for (int k = 1; k < TACO_STAMP_POINTS; ++k) acc[k] += (double)(r[k] - r[k - 1]) * 0.01;
         acc[TACO_STAMP_POINTS] += (double)(nx[0] - r[TACO_STAMP_POINTS - 1]) * 0.01;
       }
-      fprintf(stderr, "[taco stamps] workgroup %s, mean over %d frames (us):\n", wg == 0 ? "0" : "200", cnt);
+      fprintf(stderr, "[taco stamps] workgroup %s, mean over %d frames (us):\n", wg == 0 ? "0 (P group)" : wg == 1 ? "32 (Q group)" : "200", cnt);
       double tot = 0;
       for (int k = 1; k < TACO_STAMP_POINTS; ++k) { fprintf(stderr, "  %-32s %7.2f\n", names[k], acc[k] / cnt); tot += acc[k] / cnt; }
       fprintf(stderr, "  %-32s %7.2f\n  total %7.2f\n", "attn partial + frame top (mel / stop)", acc[TACO_STAMP_POINTS] / cnt, tot + acc[TACO_STAMP_POINTS] / cnt);
@@ -765,15 +773,15 @@ void taco_decoder_fill_layout(taco_dec_layout* lay, int n_wg) { fill_layout(*lay
 
 int taco_decoder_prepare(taco_handle h) {
   // the kernel needs more than the default 64 KiB of dynamic LDS
-  TACO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(taco_decoder_kernel<true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)taco_decoder_lds_bytes()));
-  TACO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(taco_decoder_kernel<false>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)taco_decoder_lds_bytes()));
-  int per_cu = 0;
-  TACO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, taco_decoder_kernel<true>, NT, taco_decoder_lds_bytes()));
-  if (per_cu < 1) TACO_FAIL(TACO_EINVAL, "decoder kernel does not fit on a CU (occupancy query returned %d)", per_cu);
-  TACO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, taco_decoder_kernel<false>, NT, taco_decoder_lds_bytes()));
-  if (per_cu < 1) TACO_FAIL(TACO_EINVAL, "decoder kernel does not fit on a CU (occupancy query returned %d)", per_cu);
+  const void* kernels[4] = {reinterpret_cast<const void*>(taco_decoder_kernel<true, 1>), reinterpret_cast<const void*>(taco_decoder_kernel<true, 2>),
+                            reinterpret_cast<const void*>(taco_decoder_kernel<false, 1>), reinterpret_cast<const void*>(taco_decoder_kernel<false, 2>)};
+  for (const void* k : kernels) {
+    // the kernel needs more than the default 64 KiB of dynamic LDS; one workgroup must fit on a CU
+    TACO_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)taco_decoder_lds_bytes()));
+    int per_cu = 0;
+    TACO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, NT, taco_decoder_lds_bytes()));
+    if (per_cu < 1) TACO_FAIL(TACO_EINVAL, "decoder kernel does not fit on a CU (occupancy query returned %d)", per_cu);
+  }
   (void)h;
   return TACO_OK;
 }

@@ -130,6 +130,10 @@ __device__ __forceinline__ void taco_publish_lanes(taco_granule* base, int cap, 
   if (lane < R) __hip_atomic_store((taco_ggran*)base + (size_t)lane * cap + idx, word, TACO_RLX_AGENT);
 }
 
+#ifndef TACO_POLL_SLEEP
+#define TACO_POLL_SLEEP 1        // x 64 clocks between two polls of a granule that has not arrived
+#endif
+
 struct taco_wait_ctx {
   taco_gu32* abort_word;     // global abort flag
   int failed;                // sticky, per thread
@@ -148,7 +152,7 @@ __device__ __forceinline__ float taco_wait_one(const taco_granule* base, int idx
   unsigned spins = 0;
   while ((unsigned)(word >> 32) != epoch) {
     if (ctx.failed) break;
-    __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_s_sleep(TACO_POLL_SLEEP);
     if ((++spins & 255u) == 0u) {
       if (__hip_atomic_load(ctx.abort_word, TACO_RLX_AGENT) != 0u) { ctx.failed = 1; break; }
       if (spins >= TACO_SPIN_LIMIT) {

@@ -179,12 +179,13 @@ def test_synthesizer_matches_reference_records(gate_table):
 
 
 def test_edge_cases_against_oracle(gate_table):
-  """One-symbol utterances, a single decoder step, the stop firing exactly on the last allowed step."""
+  """One-symbol utterances, a single decoder step, inputs around the 256-position boundary of the
+  folded-context chunks and at the 512-position capacity, the stop firing exactly on the last allowed step."""
   gate = gate_table["tiny"]
   om = oracle_model("tiny", gate)
   gm = gpu_model("tiny", gate)
   ck = scenario_checkpoint("tiny", gate)
-  for T_in, max_steps in ((1, 7), (2, 1), (3, 30), (40, 25)):
+  for T_in, max_steps in ((1, 7), (2, 1), (3, 30), (40, 25), (255, 9), (256, 9), (257, 9), (300, 12), (512, 6)):
     ids = scenarios.random_ids(ck, [T_in], seed=500 + T_in)
     masks = prenet_keep_masks(9, max_steps, om.dims.P)
     mem_o, pm_o = om.encode(chans(ids), ids["speakers"], None)
@@ -205,6 +206,30 @@ def test_edge_cases_against_oracle(gate_table):
   torch.manual_seed(meta["seed"])
   out = gm.inference(dev(ids["symbols"]), dev(ids["stresses"]), None, None, dev(ids["speakers"]), n - 1)
   assert out[0].shape[2] == n - 1 and out[4] is True
+
+
+def test_long_input_full_size_model(gate_table):
+  """Default-geometry model with more than 256 input positions (two folded-context chunks, several
+  position tiles per wave in the location term), against the oracle."""
+  gate = gate_table["ljs"]
+  om = oracle_model("ljs", gate)
+  gm = gpu_model("ljs", gate)
+  ck = scenario_checkpoint("ljs", gate)
+  for T_in, max_steps in ((384, 8), (512, 5)):
+    ids = scenarios.random_ids(ck, [T_in], seed=900 + T_in)
+    masks = prenet_keep_masks(3, max_steps, om.dims.P)
+    mem_o, pm_o = om.encode(chans(ids), ids["speakers"], None)
+    mel_o, gate_o, align_o, nf_o, reached_o, _ = om.decode(mem_o, pm_o, None, masks.numpy(), max_steps, gate_threshold=2.0)
+    mem, pm = gm.encode([dev(c) for c in chans(ids)], dev(ids["speakers"]), None)
+    mel, gate_g, align, nf, reached = gm.decode(mem, pm, None, masks, max_steps, gate_threshold=2.0)
+    assert int(nf[0]) == max_steps
+    np.testing.assert_allclose(mel[0].cpu().numpy(), mel_o[0], atol=FREE_TOL, rtol=0)
+    np.testing.assert_allclose(gate_g[0].cpu().numpy(), gate_o[0], atol=FREE_TOL, rtol=0)
+    np.testing.assert_allclose(align[0].cpu().numpy(), align_o[0], atol=FREE_TOL, rtol=0)
+  with pytest.raises(Exception):
+    ids = scenarios.random_ids(ck, [513], seed=1)
+    mem, pm = gm.encode([dev(c) for c in chans(ids)], dev(ids["speakers"]), None)
+    gm.decode(mem, pm, None, prenet_keep_masks(3, 2, om.dims.P), 2)
 
 
 def test_full_size_properties(gate_table):

@@ -466,7 +466,10 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
     if (act_d) dot_chunks<TACO_ND>(wd[0] + TACO_NA + NCTX, wd[1] + TACO_NA + NCTX, lds + L_XDH, lane, acc_d);
 
     // ============ S4: query rows and energy partial sums (Q group) ============
-    taco_gather<NT>(g + a.lay.ah + (j % TACO_REP_BIG) * a.lay.ah_cap, Ra, ep, lds + L_XAH, wctx, 0x500u);
+    // only the Q group is in a hurry for the attention hidden state, only the P and M groups for the
+    // decoder hidden state: everyone else keeps its pollers away until the first granules have arrived
+    if (!is_q) taco_gather_late<NT>(g + a.lay.ah + (j % TACO_REP_BIG) * a.lay.ah_cap, Ra, ep, lds + L_XAH, wctx, 0x500u);
+    else taco_gather<NT>(g + a.lay.ah + (j % TACO_REP_BIG) * a.lay.ah_cap, Ra, ep, lds + L_XAH, wctx, 0x500u);
     TACO_STAMP(4);
     if (is_q) {
       // wave w: query values of dimensions 2w, 2w+1, then their energy terms for every position (lane =
@@ -575,7 +578,8 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
 
     // ============ S8: mel / stop-token projection rows (M group), next frame's prenet layer 1 (P group) ============
     if (is_p) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // next frame's keep bytes (LDS-DMA) have landed
-    taco_gather<NT>(g + a.lay.dh + (j % TACO_REP_BIG) * a.lay.dh_cap, Rd, ep, lds + L_XDH, wctx, 0x900u);
+    if (!is_p && !is_m) taco_gather_late<NT>(g + a.lay.dh + (j % TACO_REP_BIG) * a.lay.dh_cap, Rd, ep, lds + L_XDH, wctx, 0x900u);
+    else taco_gather<NT>(g + a.lay.dh + (j % TACO_REP_BIG) * a.lay.dh_cap, Rd, ep, lds + L_XDH, wctx, 0x900u);
     TACO_STAMP(10);
     if (own_m) {
       acc_p += row_partial<TACO_ND>(my_proj, lds + L_XDH, lane);

@@ -189,16 +189,16 @@ __device__ __forceinline__ float row_partial(const float* w_lds, const float* x_
 }
 
 // Applies the four LSTM gate non-linearities in four lanes at once and finishes the cell update:
-// lanes 4u..4u+3 of wave 0 hold gates i, f, g, o of unit u.  Returns h' in lane 4u (valid there).
+// lanes 4u..4u+3 of wave 0 hold gates i, f, g, o of unit u.  Returns h' in all four lanes of the unit.
 __device__ __forceinline__ float lstm_cell_lanes(const float* gates_lds, const float* bias_lds, float* cell_lds,
                                                  int lane) {
   const int u = lane >> 2, gi = lane & 3;
   const float pre = gates_lds[lane & 15] + bias_lds[lane & 15];
   const float act = gi == 2 ? taco_tanh(pre) : taco_sigmoid(pre);
-  const float ig = __shfl(act, (lane & ~3) + 0, 64);
-  const float fg = __shfl(act, (lane & ~3) + 1, 64);
-  const float gg = __shfl(act, (lane & ~3) + 2, 64);
-  const float og = __shfl(act, (lane & ~3) + 3, 64);
+  const float ig = taco_quad_bcast<0>(act);
+  const float fg = taco_quad_bcast<1>(act);
+  const float gg = taco_quad_bcast<2>(act);
+  const float og = taco_quad_bcast<3>(act);
   const float c = fg * cell_lds[u & 3] + ig * gg;
   const float hv = og * taco_tanh(c);
   if (gi == 0 && u < 4) cell_lds[u] = c;
@@ -458,7 +458,8 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
     if (wave == 0) {
       const float hv = lstm_cell_lanes(lds + L_GATES, lds + L_BIAS, lds + L_CELLS, lane);
       const int u = lane >> 2;
-      if ((lane & 3) == 0 && u < Ua && j * Ua + u < Ra) taco_publish_rep<TACO_REP_BIG>(g + a.lay.ah, a.lay.ah_cap, j * Ua + u, ep, hv);
+      if (u < Ua && j * Ua + u < Ra)      // the four lanes of a unit hold the same value: they share the replicas
+        for (int r = lane & 3; r < TACO_REP_BIG; r += 4) taco_publish(g + a.lay.ah + (size_t)r * a.lay.ah_cap, j * Ua + u, ep, hv);
     }
     TACO_STAMP(3);
     // meanwhile: decoder-LSTM partial over the previous decoder hidden state
@@ -568,7 +569,8 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
     if (wave == 0) {
       const float hv = lstm_cell_lanes(lds + L_GATES, lds + L_BIAS + 16, lds + L_CELLS + 4, lane);
       const int u = lane >> 2;
-      if ((lane & 3) == 0 && u < Ud && j * Ud + u < Rd) taco_publish_rep<TACO_REP_BIG>(g + a.lay.dh, a.lay.dh_cap, j * Ud + u, ep, hv);
+      if (u < Ud && j * Ud + u < Rd)
+        for (int r = lane & 3; r < TACO_REP_BIG; r += 4) taco_publish(g + a.lay.dh + (size_t)r * a.lay.dh_cap, j * Ud + u, ep, hv);
     }
     TACO_STAMP(8);
     // meanwhile: folded-context half of my projection rows (M group)

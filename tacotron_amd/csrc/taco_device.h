@@ -72,6 +72,9 @@ __device__ __forceinline__ float taco_sum4(float v) {
   v += taco_dpp_rot<0x4E>(v);
   return v;
 }
+// Lane K of each quad, to all four lanes of the quad (quad_perm [K,K,K,K]).
+template <int K>
+__device__ __forceinline__ float taco_quad_bcast(float v) { return taco_dpp_rot<K * 0x55>(v); }
 __device__ __forceinline__ float taco_wave_max(float v) {
   v = fmaxf(v, taco_dpp_rot<0x128>(v));
   v = fmaxf(v, taco_dpp_rot<0x124>(v));
@@ -106,6 +109,8 @@ __device__ __forceinline__ float taco_sum4(float v) {
   v += __shfl_xor(v, 1, 64);
   return v;
 }
+template <int K>
+__device__ __forceinline__ float taco_quad_bcast(float v) { return __shfl(v, (threadIdx.x & 60) + K, 64); }
 #endif
 
 // ---- hand-off: one 8-byte word carries {epoch, fp32}; the data is its own flag -------------------

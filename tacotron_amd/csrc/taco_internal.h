@@ -44,9 +44,14 @@ typedef unsigned long long taco_granule;
 // Granule vectors of the decoder, in units of granules from the base; two parities each.  A vector
 // is stored in several identical replicas (producers write all, consumer workgroup j polls replica
 // j % R): 256 pollers on the few cache lines of a short vector is what limits a hand-off's latency.
-constexpr int TACO_REP_SMALL = 8;   // prenet output, frame output (<= 256 granules)
-constexpr int TACO_REP_PE = 4;      // energy partial sums (8 groups x positions)
-constexpr int TACO_REP_BIG = 2;     // LSTM hidden states (1024 granules)
+#ifndef TACO_RS
+#define TACO_RS 16
+#define TACO_RP 8
+#define TACO_RB 4
+#endif
+constexpr int TACO_REP_SMALL = TACO_RS;   // prenet layer outputs, stop token (<= 256 granules)
+constexpr int TACO_REP_PE = TACO_RP;      // energy partial sums (8 groups x positions)
+constexpr int TACO_REP_BIG = TACO_RB;     // LSTM hidden states (1024 granules)
 struct taco_dec_layout {
   int32_t h1, p, ah, pe, dh, mel;                // offsets of replica 0
   int32_t h1_cap, p_cap, ah_cap, pe_cap, dh_cap, mel_cap;   // replica strides

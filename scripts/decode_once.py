@@ -16,6 +16,9 @@ ckpt = scenarios.checkpoint("ljs")
 hp = get_hparams(ckpt)
 m = Tacotron2(hp, **abi.mapping_counts(ckpt, hp)); m.load_state_dict(ckpt["model_state"]); m.to("cuda:0")
 sym, st, spk = bench.build_inputs(ckpt)
+if len(sys.argv) > 3:                       # optional: synthetic input of that many symbols instead of the North-Wind line
+  ids = scenarios.random_ids(ckpt, [int(sys.argv[3])], seed=77)
+  sym, st, spk = ids["symbols"], ids["stresses"], ids["speakers"]
 d = lambda a: torch.from_numpy(a).to("cuda:0")
 masks = prenet_keep_masks(1111, frames, m.dims.P).to("cuda:0")
 times = []
@@ -27,5 +30,5 @@ for _ in range(reps):
   us, fr = m.last_decode_timing()
   times.append(us / fr)
 times = sorted(times[1:] or times)
-print(f"decode {fr} frames: min {times[0]:.2f} median {times[len(times) // 2]:.2f} max {times[-1]:.2f} us/frame "
+print(f"T_in={sym.shape[1]} decode {fr} frames: min {times[0]:.2f} median {times[len(times) // 2]:.2f} max {times[-1]:.2f} us/frame "
       f"({len(times)} timed runs) [{os.environ.get('TACO_HIP_LIB', 'product')}]")

@@ -228,7 +228,7 @@ extern "C" int taco_create(const taco_dims* dims, const taco_weights* weights, i
   // ---- hand-off words, control blocks, events ----
   taco_decoder_fill_layout(&h->dec_lay, h->n_cu);
   TACO_CREATE_HIP(hipMalloc((void**)&h->dec_gran, taco_decoder_granules(h->n_cu) * sizeof(taco_granule)));
-  h->enc_gran_count = 2 * 2 * 512;
+  h->enc_gran_count = taco_enc_lstm_granules();
   TACO_CREATE_HIP(hipMalloc((void**)&h->enc_gran, h->enc_gran_count * sizeof(taco_granule)));
   TACO_CREATE_HIP(hipMalloc((void**)&h->dec_ctl, sizeof(taco_dec_ctl)));
   TACO_CREATE_HIP(hipMalloc((void**)&h->enc_ctl, 64));

@@ -120,6 +120,7 @@ int taco_launch_conv(const float* in, float* out, const float* w, const float* b
                      int c_out, int k, int T, int act, int layout, hipStream_t s);
 int taco_launch_enc_lstm(taco_handle h, const float* gx, const int32_t* lens, int B, int T, float* memory,
                          hipStream_t s);
+size_t taco_enc_lstm_granules();
 int taco_launch_memory_tail(taco_handle h, const int64_t* speakers, const int32_t* lens, int B, int T,
                             float* memory, float* pm, hipStream_t s);
 int taco_launch_loc_fold(const float* dense_w, const float* conv_w, int A, int F, int K, int rows, float* out, hipStream_t s);

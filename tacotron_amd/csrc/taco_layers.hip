@@ -179,14 +179,21 @@ __global__ __launch_bounds__(256) void taco_conv_kernel(const float* __restrict_
 
 // ------------------------------------------------------------------------------------------------
 // Encoder BiLSTM recurrence, one utterance per launch.  The input projections W_ih x_t + b_ih + b_hh
-// of all steps are computed beforehand (a kernel-size-1 conv); this kernel runs the sequential part:
-// 2 * ceil(H/4) resident workgroups (one half per direction), recurrent rows in registers, hidden
-// state exchanged per step through tagged granules (double-buffered by step parity).
+// of all steps are computed beforehand (a kernel-size-1 convolution); this kernel runs the sequential
+// part.  Few, fat workgroups: a hand-off between 9 workgroups is much cheaper than one between 65.
+// A workgroup of 1024 threads owns 32 hidden units of one direction = 128 gate rows, 8 lanes per row:
+// lane `part` of a row keeps the row's columns 32k + 4 part .. +3 in registers (one ds_read_b128 of the
+// hidden vector per k), the 8 partial sums meet by DPP, the 4 gates of a unit sit in 32 adjacent lanes
+// of one wave.  The hidden state travels through tagged granules (double-buffered by step parity,
+// EL_REP replicas).
 // reference: nn.LSTM(bidirectional) in Encoder.inference, src/tacotron/model.py:253-260, 280-289;
 // for padded batches the reverse direction starts at each utterance's own last symbol
 // (pack_padded_sequence semantics, model.py:262-278).
 // ------------------------------------------------------------------------------------------------
-constexpr int EL_CH = 2;   // recurrent row chunks of 256 -> H_e <= 512
+constexpr int EL_UNITS = 32;          // hidden units per workgroup
+constexpr int EL_HMAX = 512;          // hidden width capacity
+constexpr int EL_REP = 4;             // replicas of the hidden-state vector
+constexpr int EL_GRAN_DIR = 2 * EL_REP * EL_HMAX;   // granules per direction: 2 parities x replicas x width
 
 struct EncLstmArgs {
   const float* w_hh[2];   // [4H][H]
@@ -195,74 +202,83 @@ struct EncLstmArgs {
   const int32_t* lens;    // device, or NULL = T symbols
   int b;                  // utterance index into lens
   int H, T, M, n_wg_dir;
-  taco_granule* gran;     // [2 dirs][2 parities][512]
+  taco_granule* gran;     // [2 dirs][2 parities][EL_REP][EL_HMAX]
   uint32_t* ctl;
 };
 
+// KC = 32-column chunks of a row held in registers (4 weights per lane and chunk): H <= 32 KC
+template <int KC>
 __global__ __launch_bounds__(1024) void taco_enc_lstm_kernel(const EncLstmArgs a) {
-  __shared__ __attribute__((aligned(16))) float xh[EL_CH * TACO_CHUNK];
-  __shared__ float gates[16];
-  __shared__ float cells[4];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ __attribute__((aligned(16))) float xh[EL_HMAX];
+  __shared__ int gave_up;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int len = a.lens ? a.lens[a.b] : a.T;
   const int dir = blockIdx.x / a.n_wg_dir;
   const int jj = blockIdx.x % a.n_wg_dir;
-  const int unit = wave >> 2, gate_id = wave & 3;
-  const int gu = jj * 4 + unit;
+  const int r = tid >> 3, part = tid & 7;          // gate row of this workgroup, 8 lanes per row
+  const int unit = r >> 2, gate_id = r & 3;        // rows 4u..4u+3 = gates i, f, g, o of unit u
+  const int gu = jj * EL_UNITS + unit;
   const bool active = gu < a.H;
   const int row = gate_id * a.H + gu;
-  float wr[EL_CH][4];
+  float wr[KC][4];
 #pragma unroll
-  for (int c = 0; c < EL_CH; ++c)
+  for (int k = 0; k < KC; ++k)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int col = c * TACO_CHUNK + lane * 4 + e;
-      wr[c][e] = (active && col < a.H) ? a.w_hh[dir][(size_t)row * a.H + col] : 0.0f;
+      const int col = 32 * k + 4 * part + e;
+      wr[k][e] = (active && col < a.H) ? a.w_hh[dir][(size_t)row * a.H + col] : 0.0f;
     }
-  for (int i = tid; i < EL_CH * TACO_CHUNK; i += 1024) xh[i] = 0.0f;
-  if (tid < 4) cells[tid] = 0.0f;
+  for (int i = tid; i < EL_HMAX; i += 1024) xh[i] = 0.0f;
+  if (tid == 0) gave_up = 0;
   __syncthreads();
 
   taco_wait_ctx wctx;
   wctx.abort_word = (taco_gu32*)a.ctl;
   wctx.failed = 0;
-  taco_granule* gdir = a.gran + (size_t)dir * 2 * 512;
+  taco_granule* gdir = a.gran + (size_t)dir * EL_GRAN_DIR;
   const float* gx = a.gx + (size_t)dir * 4 * a.H * a.T;
+  const bool gate_lane = active && part == 0;      // finishes its row's gate
+  const bool unit_lane = gate_lane && gate_id == 0;  // finishes its unit's cell update
+  float cell = 0.0f;
+  const int my_rep = blockIdx.x % EL_REP;
 
   for (int s = 0; s < len; ++s) {
     const int t = dir == 0 ? s : len - 1 - s;
     float gx_v = 0.0f;
-    if (active && lane == 0) gx_v = gx[(size_t)row * a.T + t];
+    if (gate_lane) gx_v = gx[(size_t)row * a.T + t];   // in flight during the wait below
     if (s > 0) {
-      taco_gather<1024>(gdir + (size_t)((s - 1) & 1) * 512, a.H, (unsigned)s, xh, wctx, 0xE00u);
-      if (__syncthreads_or(wctx.failed)) break;
-        }
-    if (active) {
-      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+      // collect h_{s-1}; a give-up is passed on through LDS, so that the barrier orders LDS traffic only
+      // (a full __syncthreads would also wait for this wave's publish stores to be acknowledged: ~1 us)
+      if (tid < a.H) xh[tid] = taco_wait_one(gdir + ((size_t)((s - 1) & 1) * EL_REP + my_rep) * EL_HMAX, tid, (unsigned)s, wctx, 0xE00u);
+      if (wctx.failed) gave_up = 1;
+      taco_lds_barrier();
+      if (gave_up) break;
+    }
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int c = 0; c < EL_CH; ++c) {
-        const float4 x = *reinterpret_cast<const float4*>(xh + c * TACO_CHUNK + lane * 4);
-        acc[0] = fmaf(wr[c][0], x.x, acc[0]);
-        acc[1] = fmaf(wr[c][1], x.y, acc[1]);
-        acc[2] = fmaf(wr[c][2], x.z, acc[2]);
-        acc[3] = fmaf(wr[c][3], x.w, acc[3]);
-      }
-      const float sum = taco_wave_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));
-      if (lane == 0) gates[wave] = gx_v + sum;
+    for (int k = 0; k < KC; ++k) {
+      const float4 x = *reinterpret_cast<const float4*>(xh + 32 * k + 4 * part);
+      acc[0] = fmaf(wr[k][0], x.x, acc[0]);
+      acc[1] = fmaf(wr[k][1], x.y, acc[1]);
+      acc[2] = fmaf(wr[k][2], x.z, acc[2]);
+      acc[3] = fmaf(wr[k][3], x.w, acc[3]);
     }
-    __syncthreads();
-    if (tid < 4 && jj * 4 + tid < a.H) {
-      const float ig = taco_sigmoid(gates[tid * 4 + 0]);
-      const float fg = taco_sigmoid(gates[tid * 4 + 1]);
-      const float gg = tanhf(gates[tid * 4 + 2]);
-      const float og = taco_sigmoid(gates[tid * 4 + 3]);
-      const float c = fg * cells[tid] + ig * gg;
-      cells[tid] = c;
-      const float hv = og * tanhf(c);
-      taco_publish(gdir + (size_t)(s & 1) * 512, jj * 4 + tid, (unsigned)s + 1u, hv);
-      a.memory[(size_t)t * a.M + dir * a.H + jj * 4 + tid] = hv;
+    const float pre = gx_v + taco_sum8((acc[0] + acc[1]) + (acc[2] + acc[3]));
+    const float act = gate_id == 2 ? taco_tanh(pre) : taco_sigmoid(pre);     // valid in the row's lane 0
+    // the unit's four gates sit 8 lanes apart in this half-wave
+    const int base = lane & 32;
+    const float ig = __shfl(act, base + 0, 64);
+    const float fg = __shfl(act, base + 8, 64);
+    const float gg = __shfl(act, base + 16, 64);
+    const float og = __shfl(act, base + 24, 64);
+    if (unit_lane) {
+      cell = fg * cell + ig * gg;
+      const float hv = og * taco_tanh(cell);
+      taco_publish_rep<EL_REP>(gdir + (size_t)(s & 1) * EL_REP * EL_HMAX, EL_HMAX, gu, (unsigned)s + 1u, hv);
+      a.memory[(size_t)t * a.M + dir * a.H + gu] = hv;
     }
-    __syncthreads();
+    taco_lds_barrier();  // every thread is done with xh before the next step overwrites it (LDS only: the
+                         // publish stores stay in flight)
   }
 }
 
@@ -386,9 +402,10 @@ int taco_launch_conv(const float* in, float* out, const float* w, const float* b
 int taco_launch_enc_lstm(taco_handle h, const float* gx, const int32_t* lens, int B, int T, float* memory,
                          hipStream_t s) {
   const taco_dims& d = h->d;
-  const int n_wg_dir = (d.H_e + 3) / 4;
-  if (d.H_e > EL_CH * TACO_CHUNK || 2 * n_wg_dir > h->n_cu)
-    TACO_FAIL(TACO_EINVAL, "encoder LSTM width %d exceeds the recurrence kernel's capacity", d.H_e);
+  const int n_wg_dir = (d.H_e + EL_UNITS - 1) / EL_UNITS;
+  if (d.H_e > EL_HMAX || 2 * n_wg_dir > h->n_cu)
+    TACO_FAIL(TACO_EINVAL, "encoder LSTM width %d exceeds the recurrence kernel's capacity %d", d.H_e, EL_HMAX);
+  if (h->enc_gran_count < (size_t)2 * EL_GRAN_DIR) TACO_FAIL(TACO_EINVAL, "encoder hand-off buffer too small");
   for (int b = 0; b < B; ++b) {
     EncLstmArgs a;
     a.w_hh[0] = h->w.enc_lstm_w_hh[0];
@@ -399,11 +416,17 @@ int taco_launch_enc_lstm(taco_handle h, const float* gx, const int32_t* lens, in
     a.H = d.H_e; a.T = T; a.M = d.M; a.n_wg_dir = n_wg_dir;
     a.gran = h->enc_gran; a.ctl = h->enc_ctl;
     TACO_HIP(hipMemsetAsync(h->enc_gran, 0, h->enc_gran_count * sizeof(taco_granule), s));
-    hipLaunchKernelGGL(taco_enc_lstm_kernel, dim3(2 * n_wg_dir), dim3(1024), 0, s, a);
+    const dim3 grid(2 * n_wg_dir), block(1024);
+    if (d.H_e <= 128) hipLaunchKernelGGL(taco_enc_lstm_kernel<4>, grid, block, 0, s, a);
+    else if (d.H_e <= 256) hipLaunchKernelGGL(taco_enc_lstm_kernel<8>, grid, block, 0, s, a);
+    else if (d.H_e <= 384) hipLaunchKernelGGL(taco_enc_lstm_kernel<12>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(taco_enc_lstm_kernel<16>, grid, block, 0, s, a);
     TACO_HIP(hipGetLastError());
   }
   return TACO_OK;
 }
+
+size_t taco_enc_lstm_granules() { return (size_t)2 * EL_GRAN_DIR; }
 
 int taco_launch_memory_tail(taco_handle h, const int64_t* speakers, const int32_t* lens, int B, int T,
                             float* memory, float* pm, hipStream_t s) {

@@ -33,6 +33,7 @@ extern "C" {
 #define TACO_EINVAL (-22)     /* bad argument or unsupported extent */
 #define TACO_ENOMEM (-12)     /* device allocation failed */
 #define TACO_EHIP (-5)        /* a HIP runtime call failed */
+#define TACO_ERANGE (-34)     /* an input id lies outside its table (reported at the next synchronising call) */
 #define TACO_ETIMEDOUT (-110) /* the persistent decoder gave up waiting on a hand-off */
 
 /* Tensor extents of one checkpoint (reference: src/tacotron/model.py:220-260, 293-356). */
@@ -158,6 +159,14 @@ int taco_decode(taco_handle h, const float* memory, const float* processed_memor
                 int32_t B, int32_t T_in, const uint8_t* masks, int32_t T_cap, int32_t max_steps,
                 float gate_threshold, const float* forced_mel, float* mel, float* gate, float* align,
                 int32_t* n_frames, uint8_t* reached_max, void* stream);
+
+/* Waits for the work enqueued on `stream` and reports what the encoder stage found: TACO_ERANGE when
+ * an id passed to taco_encode was outside its embedding table / one-hot width (the reference's
+ * nn.Embedding / F.one_hot raise for those: src/tacotron/model.py:585-609), TACO_ETIMEDOUT when the
+ * encoder recurrence gave up on a hand-off, else 0.  The flags are cleared by the call.
+ * taco_encode itself never blocks; taco_decode performs the same check at its own synchronisation,
+ * so calling this is optional. */
+int taco_encode_status(taco_handle h, void* stream);
 
 /* mel + postnet(mel).  Replaces Postnet.forward and the residual add
  * (reference: src/tacotron/model.py:205-211, 788-789).

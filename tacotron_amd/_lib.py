@@ -19,7 +19,7 @@ CSRC_DIR = os.path.join(_PKG_DIR, "csrc")
 
 EXPORTED_SYMBOLS = (
   "taco_last_error", "taco_version", "taco_create", "taco_destroy", "taco_step_weight_bytes",
-  "taco_encode", "taco_decode", "taco_postnet", "taco_last_decode_timing",
+  "taco_encode", "taco_encode_status", "taco_decode", "taco_postnet", "taco_last_decode_timing",
 )
 
 _lib: Optional[C.CDLL] = None
@@ -59,6 +59,7 @@ def lib() -> C.CDLL:
   L.taco_step_weight_bytes.argtypes = [vp]
   L.taco_step_weight_bytes.restype = C.c_int64
   L.taco_encode.argtypes = [vp, C.POINTER(vp), vp, vp, i32, i32, vp, vp, vp]
+  L.taco_encode_status.argtypes = [vp, vp]
   L.taco_decode.argtypes = [vp, vp, vp, vp, i32, i32, vp, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp]
   L.taco_postnet.argtypes = [vp, vp, vp, i32, i32, vp, vp]
   L.taco_last_decode_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i32)]
@@ -66,6 +67,14 @@ def lib() -> C.CDLL:
   return L
 
 
+ERANGE = -34
+
+
+class TacoIndexError(TacoError, IndexError):
+  """An input id outside its table (what the reference's embedding lookup raises an IndexError for)."""
+
+
 def check(rc: int) -> None:
   if rc != 0:
-    raise TacoError(rc, lib().taco_last_error().decode("utf-8", "replace"))
+    message = lib().taco_last_error().decode("utf-8", "replace")
+    raise (TacoIndexError if rc == ERANGE else TacoError)(rc, message)

@@ -233,6 +233,7 @@ extern "C" int taco_create(const taco_dims* dims, const taco_weights* weights, i
   TACO_CREATE_HIP(hipMalloc((void**)&h->dec_ctl, sizeof(taco_dec_ctl)));
   TACO_CREATE_HIP(hipMalloc((void**)&h->enc_ctl, 64));
   TACO_CREATE_HIP(hipMemset(h->enc_ctl, 0, 64));
+  TACO_CREATE_HIP(hipHostMalloc((void**)&h->enc_ctl_host, 64, hipHostMallocDefault));
   TACO_CREATE_HIP(hipHostMalloc((void**)&h->dec_ctl_host, sizeof(taco_dec_ctl), hipHostMallocDefault));
   TACO_CREATE_HIP(hipEventCreate(&h->ev_start));
   TACO_CREATE_HIP(hipEventCreate(&h->ev_stop));
@@ -258,6 +259,7 @@ extern "C" int taco_destroy(taco_handle h) {
   if (h->dec_ctl) (void)hipFree(h->dec_ctl);
   if (h->enc_ctl) (void)hipFree(h->enc_ctl);
   if (h->dec_ctl_host) (void)hipHostFree(h->dec_ctl_host);
+  if (h->enc_ctl_host) (void)hipHostFree(h->enc_ctl_host);
   if (h->ev_start) (void)hipEventDestroy(h->ev_start);
   if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
   delete h;
@@ -311,6 +313,26 @@ extern "C" int taco_encode(taco_handle h, const int64_t* const* ids, const int64
   rc = taco_launch_enc_lstm(h, h->ws_gx, lens, B, T_in, memory, s);
   if (rc != TACO_OK) return rc;
   return taco_launch_memory_tail(h, speakers, lens, B, T_in, memory, processed_memory, s);
+}
+
+int taco_check_encoder_flags(taco_handle h, hipStream_t s) {
+  const uint32_t abort_code = h->enc_ctl_host[0], info = h->enc_ctl_host[1], bad = h->enc_ctl_host[2];
+  if (abort_code == 0 && bad == 0) return TACO_OK;
+  TACO_HIP(hipMemsetAsync(h->enc_ctl, 0, 64, s));
+  if (bad != 0) {
+    if (bad > (uint32_t)TACO_MAX_CHANNELS) TACO_FAIL(TACO_ERANGE, "a speaker id passed to taco_encode is outside the speaker table");
+    TACO_FAIL(TACO_ERANGE, "an id of input channel %u passed to taco_encode is outside its table", bad - 1u);
+  }
+  TACO_FAIL(TACO_ETIMEDOUT, "encoder recurrence hand-off wait gave up (code %u, info 0x%x)", abort_code, info);
+}
+
+extern "C" int taco_encode_status(taco_handle h, void* stream) {
+  if (!h) TACO_FAIL(TACO_EINVAL, "taco_encode_status: NULL handle");
+  hipStream_t s = (hipStream_t)stream;
+  TACO_HIP(hipSetDevice(h->device));
+  TACO_HIP(hipMemcpyAsync(h->enc_ctl_host, h->enc_ctl, 64, hipMemcpyDeviceToHost, s));
+  TACO_HIP(hipStreamSynchronize(s));
+  return taco_check_encoder_flags(h, s);
 }
 
 extern "C" int taco_decode(taco_handle h, const float* memory, const float* processed_memory, const int32_t* lens,

@@ -125,6 +125,8 @@ struct DecArgs {
   float thr;
   const float* forced_mel;
   float *mel, *gate, *align;
+  int32_t* n_frames_out;   // this utterance's entries of the caller's result arrays
+  uint8_t* reached_out;
   taco_granule* gran;
   taco_dec_layout lay;
   taco_dec_ctl* ctl;
@@ -627,8 +629,11 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
   }
 
   if (j == 0 && tid == 0) {
+    const unsigned reached = (!stopped && !forced && t == a.max_steps) ? 1u : 0u;
     a.ctl->n_frames = (uint32_t)t;
-    a.ctl->reached_max = (!stopped && !forced && t == a.max_steps) ? 1u : 0u;
+    a.ctl->reached_max = reached;
+    *a.n_frames_out = t;
+    *a.reached_out = (uint8_t)reached;
   }
 }
 
@@ -695,7 +700,7 @@ int taco_launch_decoder(taco_handle h, const float* memory, const float* pm, int
   a.dec_w_ih = w.dec_w_ih; a.dec_w_hh = w.dec_w_hh; a.dec_b_ih = w.dec_b_ih; a.dec_b_hh = w.dec_b_hh;
   a.proj_w = w.proj_w; a.proj_b = w.proj_b; a.gate_w = w.gate_w; a.gate_b = w.gate_b;
   a.pm = pm; a.G = h->ws_G; a.masks = masks; a.T_cap = T_cap; a.max_steps = max_steps; a.thr = thr;
-  a.forced_mel = forced_mel; a.mel = mel; a.gate = gate; a.align = align;
+  a.forced_mel = forced_mel; a.mel = mel; a.gate = gate; a.align = align; a.n_frames_out = n_frames; a.reached_out = reached;
   a.gran = h->dec_gran; a.lay = h->dec_lay; a.ctl = h->dec_ctl;
 
   // folded context weights of this utterance: G = ctx_w_cat [rows][M] * memory^T [M][T_in], run as a
@@ -738,7 +743,12 @@ int taco_launch_decoder(taco_handle h, const float* memory, const float* pm, int
 
   // results: frame count and flags come back through the control block
   TACO_HIP(hipMemcpyAsync(h->dec_ctl_host, h->dec_ctl, sizeof(taco_dec_ctl), hipMemcpyDeviceToHost, s));
+  TACO_HIP(hipMemcpyAsync(h->enc_ctl_host, h->enc_ctl, 64, hipMemcpyDeviceToHost, s));
   TACO_HIP(hipStreamSynchronize(s));
+  {
+    const int erc = taco_check_encoder_flags(h, s);     // what a preceding taco_encode on this stream found
+    if (erc != TACO_OK) return erc;
+  }
   if (h->dec_ctl_host->abort_code != 0)
     TACO_FAIL(TACO_ETIMEDOUT, "decoder hand-off wait gave up (code %u, info 0x%x) after %u frames",
               h->dec_ctl_host->abort_code, h->dec_ctl_host->abort_info, h->dec_ctl_host->n_frames);
@@ -766,12 +776,7 @@ int taco_launch_decoder(taco_handle h, const float* memory, const float* pm, int
     }
   }
 #endif
-  const int32_t nf = (int32_t)h->dec_ctl_host->n_frames;
-  const uint8_t rm = (uint8_t)h->dec_ctl_host->reached_max;
-  h->last_frames = nf;
-  TACO_HIP(hipMemcpyAsync(n_frames, &nf, sizeof(nf), hipMemcpyHostToDevice, s));
-  TACO_HIP(hipMemcpyAsync(reached, &rm, sizeof(rm), hipMemcpyHostToDevice, s));
-  TACO_HIP(hipStreamSynchronize(s));
+  h->last_frames = (int32_t)h->dec_ctl_host->n_frames;
   return TACO_OK;
 }
 

@@ -103,7 +103,9 @@ struct taco_handle_s {
   taco_dec_layout dec_lay;
   taco_dec_ctl* dec_ctl;     // device
   taco_dec_ctl* dec_ctl_host;  // pinned host mirror
-  uint32_t* enc_ctl;         // device: [0] abort code of the encoder LSTM kernel
+  uint32_t* enc_ctl;         // device: [0] abort code, [1] abort info of the encoder LSTM kernel, [2] 1 + channel of an
+                             // out-of-range input id (speakers: 1 + TACO_MAX_CHANNELS)
+  uint32_t* enc_ctl_host;    // pinned host mirror [16]
   hipEvent_t ev_start, ev_stop;
   int last_frames;
   int timing_valid;
@@ -121,6 +123,9 @@ int taco_launch_conv(const float* in, float* out, const float* w, const float* b
 int taco_launch_enc_lstm(taco_handle h, const float* gx, const int32_t* lens, int B, int T, float* memory,
                          hipStream_t s);
 size_t taco_enc_lstm_granules();
+// Reads back the encoder's flags (the caller has synchronised the stream after copying them to
+// enc_ctl_host); clears them on the device when one is set.
+int taco_check_encoder_flags(taco_handle h, hipStream_t s);
 int taco_launch_memory_tail(taco_handle h, const int64_t* speakers, const int32_t* lens, int B, int T,
                             float* memory, float* pm, hipStream_t s);
 int taco_launch_loc_fold(const float* dense_w, const float* conv_w, int A, int F, int K, int rows, float* out, hipStream_t s);

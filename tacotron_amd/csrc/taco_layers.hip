@@ -16,6 +16,7 @@ struct EmbedArgs {
   int n_channels, E, T, B;
   const int32_t* lens;
   float* x;
+  uint32_t* bad_id;      // set to 1 + channel when an id lies outside its table
 };
 
 __global__ __launch_bounds__(256) void taco_embed_kernel(const EmbedArgs a) {
@@ -35,6 +36,8 @@ __global__ __launch_bounds__(256) void taco_embed_kernel(const EmbedArgs a) {
           if (id >= 0 && id < a.rows[c]) {
             if (a.table[c]) v = a.table[c][(size_t)id * a.width[c] + (e - off)];
             else v = (id == (int64_t)(e - off)) ? 1.0f : 0.0f;
+          } else {
+            *a.bad_id = 1u + (uint32_t)c;
           }
         }
         if (c < a.n_channels) off += a.width[c];
@@ -293,6 +296,7 @@ struct TailArgs {
   const int32_t* lens;
   float* memory;           // [B][T][M]
   int T, M, S, H2, spk_rows;
+  uint32_t* bad_id;
 };
 
 __global__ __launch_bounds__(256) void taco_memory_tail_kernel(const TailArgs a) {
@@ -309,6 +313,7 @@ __global__ __launch_bounds__(256) void taco_memory_tail_kernel(const TailArgs a)
     for (int k = tid; k < a.S; k += 256) {
       float v = 0.0f;
       if (id >= 0 && id < a.spk_rows) v = a.spk_table ? a.spk_table[(size_t)id * a.S + k] : (id == k ? 1.0f : 0.0f);
+      else *a.bad_id = 1u + (uint32_t)TACO_MAX_CHANNELS;
       mem[a.H2 + k] = v;
     }
   }
@@ -368,7 +373,7 @@ int taco_launch_embed(taco_handle h, const int64_t* const* ids_dev, const int32_
     a.rows[c] = c < d.n_channels ? d.ch_rows[c] : 0;
     if (c < d.n_channels && !a.ids[c]) TACO_FAIL(TACO_EINVAL, "ids[%d] is NULL", c);
   }
-  a.n_channels = d.n_channels; a.E = d.E; a.T = T; a.B = B; a.lens = lens; a.x = x;
+  a.n_channels = d.n_channels; a.E = d.E; a.T = T; a.B = B; a.lens = lens; a.x = x; a.bad_id = h->enc_ctl + 2;
   const size_t total = (size_t)B * d.E * T;
   const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
   hipLaunchKernelGGL(taco_embed_kernel, dim3(blocks), dim3(256), 0, s, a);
@@ -436,7 +441,7 @@ int taco_launch_memory_tail(taco_handle h, const int64_t* speakers, const int32_
   TailArgs a;
   a.speakers = speakers; a.spk_table = h->w.spk_table; a.lens = lens;
   a.memory = memory; a.T = T; a.M = d.M; a.S = d.S; a.H2 = 2 * d.H_e;
-  a.spk_rows = d.spk_rows;
+  a.spk_rows = d.spk_rows; a.bad_id = h->enc_ctl + 2;
   hipLaunchKernelGGL(taco_memory_tail_kernel, dim3(T, B), dim3(256), 0, s, a);
   TACO_HIP(hipGetLastError());
   // processed_memory = memory_layer(memory): a kernel-size-1 convolution, position-major in and out

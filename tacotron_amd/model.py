@@ -122,7 +122,10 @@ class Tacotron2:
 
   # ---- stages ------------------------------------------------------------------------------------
   def encode(self, ids: Sequence[torch.Tensor], speakers: Optional[torch.Tensor],
-             lens: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
+             lens: Optional[torch.Tensor], validate: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Enqueues the encoder stage and returns at once.  Ids outside their tables are detected on the
+    device and raise an IndexError at the next synchronising call (``decode``), or right here with
+    ``validate=True`` (which waits for the stage to finish)."""
     h = self._require()
     ids = [i.to(device=self.device, dtype=torch.int64).contiguous() for i in ids]
     if len(ids) != self.cdims.n_channels:
@@ -131,15 +134,11 @@ class Tacotron2:
     for c, t in enumerate(ids):
       if tuple(t.shape) != (B, T):
         raise ValueError("id tensors differ in shape")
-      if T > 0 and (int(t.min()) < 0 or int(t.max()) >= self.cdims.ch_rows[c]):
-        raise IndexError(f"id out of range in input channel {c}")
     spk = None
     if self.dims.S > 0:
       if speakers is None:
         raise ValueError("the checkpoint models speakers: a speakers tensor is required")
       spk = speakers.to(device=self.device, dtype=torch.int64).contiguous()
-      if int(spk.min()) < 0 or int(spk.max()) >= self.cdims.spk_rows:
-        raise IndexError("speaker id out of range")
     ln = None if lens is None else lens.to(device=self.device, dtype=torch.int32).contiguous()
     memory = torch.empty(B, T, self.dims.M, device=self.device, dtype=torch.float32)
     pm = torch.empty(B, T, self.dims.A, device=self.device, dtype=torch.float32)
@@ -148,6 +147,8 @@ class Tacotron2:
       h, arr, None if spk is None else C.c_void_p(spk.data_ptr()),
       None if ln is None else C.c_void_p(ln.data_ptr()), B, T, C.c_void_p(memory.data_ptr()),
       C.c_void_p(pm.data_ptr()), self._stream()))
+    if validate:
+      _lib.check(_lib.lib().taco_encode_status(h, self._stream()))
     return memory, pm
 
   def decode(self, memory: torch.Tensor, pm: torch.Tensor, lens: Optional[torch.Tensor], masks: torch.Tensor,

@@ -271,8 +271,16 @@ def test_error_reporting():
     gm.decode(mem, pm, None, masks, 8, T_cap=4)            # max_steps beyond the output capacity
   bad = ids["symbols"].copy()
   bad[0, 0] = 10 ** 6
+  with pytest.raises(IndexError):                          # checked on the device, reported on request ...
+    gm.encode([dev(bad)] + [dev(c) for c in chans(ids)[1:]], dev(ids["speakers"]), None, validate=True)
+  mem_bad, pm_bad = gm.encode([dev(bad)] + [dev(c) for c in chans(ids)[1:]], dev(ids["speakers"]), None)
+  with pytest.raises(IndexError):                          # ... or by the next call that synchronises
+    gm.decode(mem_bad, pm_bad, None, masks, 8)
+  bad_spk = ids["speakers"].copy()
+  bad_spk[0, -1] = -1
   with pytest.raises(IndexError):
-    gm.encode([dev(bad)] + [dev(c) for c in chans(ids)[1:]], dev(ids["speakers"]), None)
+    gm.encode([dev(c) for c in chans(ids)], dev(bad_spk), None, validate=True)
+  gm.encode([dev(c) for c in chans(ids)], dev(ids["speakers"]), None, validate=True)   # flags were cleared
 
 
 def test_synthesize_command_on_gpu_matches_oracle_backed_run(tmp_path):

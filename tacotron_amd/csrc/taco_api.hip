@@ -78,6 +78,10 @@ extern "C" int taco_create(const taco_dims* dims, const taco_weights* weights, i
   if (d.H_e != (d.E + 1) / 2 || d.M != 2 * d.H_e + d.S) TACO_FAIL(TACO_EINVAL, "inconsistent extents: E=%d H_e=%d S=%d M=%d", d.E, d.H_e, d.S, d.M);
 
   TACO_HIP(hipSetDevice(device));
+  {
+    const int prc = taco_conv_prepare();
+    if (prc != TACO_OK) return prc;
+  }
   hipDeviceProp_t prop;
   TACO_HIP(hipGetDeviceProperties(&prop, device));
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) TACO_FAIL(TACO_EINVAL, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);

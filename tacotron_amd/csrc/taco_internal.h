@@ -120,6 +120,7 @@ int taco_launch_embed(taco_handle h, const int64_t* const* ids_dev, const int32_
 int taco_launch_conv(const float* in, float* out, const float* w, const float* bias, const float* alpha,
                      const float* beta, const float* residual, const int32_t* lens, int B, int c_in,
                      int c_out, int k, int T, int act, int layout, hipStream_t s);
+int taco_conv_prepare();
 int taco_launch_enc_lstm(taco_handle h, const float* gx, const int32_t* lens, int B, int T, float* memory,
                          hipStream_t s);
 size_t taco_enc_lstm_granules();

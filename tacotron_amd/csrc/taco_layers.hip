@@ -56,33 +56,41 @@ __global__ __launch_bounds__(256) void taco_embed_kernel(const EmbedArgs a) {
 // One 256-thread workgroup computes a 32-channel x 64-column output tile.  Its four waves are
 // (column half) x (half of the input channels of a slab): every wave owns one 32 x 32 accumulator
 // tile and the two channel halves are added through LDS at the end.  Input columns and weights are
-// staged through LDS in slabs of CI input channels, double-buffered: the next slab's global loads
-// are in flight while the current slab's MFMAs run.
+// staged through LDS in slabs of CI input channels, double-buffered, with the global loads running
+// TWO slabs ahead in registers: one slab's MFMAs (~1 us) do not cover a load's round trip.
 // MFMA operand maps (32x32x2): lane l supplies A[row l&31][k = l>>5] and B[k = l>>5][col l&31]; the
 // accumulator holds column l&31, rows (r&3) + 8*(r>>2) + 4*(l>>5) in register r.
 // reference: ConvNorm (src/tacotron/layers.py:17-35) + BatchNorm1d in Encoder.inference
 // (src/tacotron/model.py:280-289) and Postnet.forward (205-211); residual add model.py:788-789.
 // ------------------------------------------------------------------------------------------------
-constexpr int CV_CO = 32, CV_TT = 64;
+constexpr int CV_CO = 32, CV_TT = 64, CV_XS = 96;
+constexpr int taco_conv_ci(int ks) { return ks == 1 ? 64 : 32; }
+constexpr size_t taco_conv_lds_bytes(int ks) {
+  return sizeof(float) * 2 * ((size_t)taco_conv_ci(ks) * CV_XS + (size_t)CV_CO * (taco_conv_ci(ks) * ks + 1));
+}
 typedef float taco_f32x16 __attribute__((ext_vector_type(16)));
 
-template <int KS>
+template <int KS, bool IN_TM>
 __global__ __launch_bounds__(256) void taco_conv_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                         const float* __restrict__ w, const float* __restrict__ bias,
                                                         const float* __restrict__ alpha, const float* __restrict__ beta,
                                                         const float* __restrict__ residual, const int32_t* lens,
-                                                        int c_in, int c_out, int T, int act, int layout) {
-  const bool in_time_major = layout & 1, out_time_major = layout & 2;   // [T][C] instead of [C][T]
-  constexpr int CI = KS == 1 ? 32 : 16;        // input channels per slab
+                                                        int c_in, int c_out, int T, int act, int layout,
+                                                        const float* __restrict__ zero_word) {
+  constexpr bool in_time_major = IN_TM;          // input is [T][C] instead of [C][T]
+  const bool out_time_major = layout & 2;        // output likewise
+  constexpr int CI = taco_conv_ci(KS);         // input channels per slab
   constexpr int PAD = (KS - 1) / 2;
   constexpr int XW = CV_TT + KS - 1;           // input columns a tile needs
-  constexpr int XS = 96;                       // row stride = 32 (mod 64): the two k-lanes of an MFMA hit disjoint banks
+  constexpr int XS = CV_XS;                    // row stride = 32 (mod 64): the two k-lanes of an MFMA hit disjoint banks
   constexpr int WS = CI * KS + 1;              // odd row stride: 32 rows -> 32 banks
-  constexpr int NW = (CV_CO * CI * KS + 255) / 256;
-  constexpr int NX = (CI * XW + 255) / 256;
-  static_assert(XW <= XS && 2 * CV_CO * WS >= 2 * 16 * 64, "tile geometry");
-  __shared__ float xs[2][CI][XS];
-  __shared__ float ws[2][CV_CO][WS];
+  constexpr int RL = CI * KS;                  // weights of one output channel in a slab: contiguous in memory
+  constexpr int NW = RL / 8;                   // 8 threads per weight row, NW consecutive floats each
+  constexpr int NX = (XW + 7) / 8;             // 8 threads per input row, columns seg, seg + 8, ...
+  static_assert(XW <= XS && 2 * CV_CO * WS >= 2 * 16 * 64 && RL % 32 == 0 && CI * 8 == 256 * (CI / 32), "tile geometry");
+  extern __shared__ __attribute__((aligned(16))) float conv_lds[];
+  float (*xs)[CI][XS] = reinterpret_cast<float (*)[CI][XS]>(conv_lds);                       // [2][CI][XS]
+  float (*ws)[CV_CO][WS] = reinterpret_cast<float (*)[CV_CO][WS]>(conv_lds + 2 * CI * XS);   // [2][CV_CO][WS]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int thalf = wave & 1, khalf = wave >> 1;
   const int i = lane & 31, h = lane >> 5;
@@ -96,58 +104,85 @@ __global__ __launch_bounds__(256) void taco_conv_kernel(const float* __restrict_
   for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 
   if (t0 < len) {
-    float pw[NW], px[NX];
-    auto load_slab = [&](int ci0) {
+    // Staging map (all address arithmetic outside the slab loop): thread = (row tid >> 3, segment tid & 7).
+    // Weights: row = output channel, the thread takes NW consecutive floats of the slab's RL.  Inputs: CI / 32
+    // rows per thread (row + 32 q), columns seg + 8 n.
+    constexpr int XR = CI / 32;
+    typedef float taco_f4u __attribute__((ext_vector_type(4), aligned(4)));
+    const int srow = tid >> 3, seg = tid & 7;
+    const bool w_row_ok = co0 + srow < c_out;
+    const float* w_row = w + (size_t)(w_row_ok ? co0 + srow : 0) * c_in * KS + seg * NW;
+    float pwA[NW], pxA[XR][NX], pwB[NW], pxB[XR][NX];
+    auto load_slab = [&](int ci0, float (&pw)[NW], float (&px)[XR][NX]) {
+      // Unconditional 16-byte loads keep the slab loop free of branches.  In a ragged last slab (and in rows
+      // past c_out, which are clamped to row 0 and never stored) they run on into the following weights: finite
+      // values that meet input rows staged as zeros, so they add nothing.
+      const float* src = w_row + (size_t)ci0 * KS;
 #pragma unroll
-      for (int n = 0; n < NW; ++n) {
-        const int idx = tid + n * 256;
-        const int co = idx / (CI * KS), rem = idx % (CI * KS);
-        const bool ok = idx < CV_CO * CI * KS && co0 + co < c_out && ci0 + rem / KS < c_in;
-        pw[n] = ok ? w[((size_t)(co0 + co) * c_in + ci0) * KS + rem] : 0.0f;
+      for (int n = 0; n < NW; n += 4) {
+        const taco_f4u v = *reinterpret_cast<const taco_f4u*>(src + n);
+        pw[n] = v.x; pw[n + 1] = v.y; pw[n + 2] = v.z; pw[n + 3] = v.w;
       }
 #pragma unroll
-      for (int n = 0; n < NX; ++n) {
-        const int idx = tid + n * 256;
-        const int r = idx / XW, c = idx % XW;
-        const int tt = t0 + c - PAD, ci = ci0 + r;
-        const bool ok = idx < CI * XW && ci < c_in && tt >= 0 && tt < len;
-        px[n] = ok ? (in_time_major ? in_b[(size_t)tt * c_in + ci] : in_b[(size_t)ci * T + tt]) : 0.0f;
+      for (int q = 0; q < XR; ++q) {
+        const int ci = ci0 + srow + 32 * q;
+#pragma unroll
+        for (int n = 0; n < NX; ++n) {
+          const int c = seg + 8 * n;
+          const int tt = t0 + c - PAD;
+          const bool ok = c < XW && ci < c_in && tt >= 0 && tt < len;
+          const size_t at = in_time_major ? (size_t)tt * c_in + ci : (size_t)ci * T + tt;
+          px[q][n] = *(ok ? in_b + at : zero_word);    // padding reads a zero word in global memory: one plain
+                                                       // global load, nothing to wait for here
+        }
       }
     };
-    auto store_slab = [&](int buf) {
+    auto store_slab = [&](int buf, const float (&pw)[NW], const float (&px)[XR][NX]) {
 #pragma unroll
-      for (int n = 0; n < NW; ++n) {
-        const int idx = tid + n * 256;
-        if (idx < CV_CO * CI * KS) ws[buf][idx / (CI * KS)][idx % (CI * KS)] = pw[n];
-      }
+      for (int n = 0; n < NW; ++n) ws[buf][srow][seg * NW + n] = pw[n];
 #pragma unroll
-      for (int n = 0; n < NX; ++n) {
-        const int idx = tid + n * 256;
-        if (idx < CI * XW) xs[buf][idx / XW][idx % XW] = px[n];
-      }
+      for (int q = 0; q < XR; ++q)
+#pragma unroll
+        for (int n = 0; n < NX; ++n)
+          if (seg + 8 * n < XW) xs[buf][srow + 32 * q][seg + 8 * n] = px[q][n];
     };
     const int n_slabs = (c_in + CI - 1) / CI;
-    load_slab(0);
-    store_slab(0);
-    __syncthreads();
-    for (int s = 0; s < n_slabs; ++s) {
+    // one slab: fetch slab s+2 into `fetch`, multiply slab s (LDS buffer s&1), park slab s+1 (`park`, fetched
+    // one slab ago) in the other LDS buffer
+    auto slab = [&](int s, float (&fw)[NW], float (&fx)[XR][NX], const float (&kw)[NW], const float (&kx)[XR][NX]) {
       const int buf = s & 1;
-      if (s + 1 < n_slabs) load_slab((s + 1) * CI);
-#pragma unroll
-      for (int step = 0; step < CI / 4; ++step) {
+      load_slab(min(s + 2, n_slabs - 1) * CI, fw, fx);      // past the end: a harmless reload of the last slab
+      // operands of step+1 are read from LDS while the MFMAs of step run (two register sets)
+      float av[2][KS], bv[2][KS];
+      auto read_operands = [&](int step, int set) {
         const int cl = khalf * (CI / 2) + step * 2 + h;    // this lane's input channel of the k-pair
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) {
-          const float av = ws[buf][i][cl * KS + kk];
-          const float bv = xs[buf][cl][thalf * 32 + i + kk];
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+          av[set][kk] = ws[buf][i][cl * KS + kk];
+          bv[set][kk] = xs[buf][cl][thalf * 32 + i + kk];
         }
+      };
+      read_operands(0, 0);
+#pragma unroll
+      for (int step = 0; step < CI / 4; ++step) {
+        if (step + 1 < CI / 4) read_operands(step + 1, (step + 1) & 1);
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[step & 1][kk], bv[step & 1][kk], acc, 0, 0, 0);
       }
-      if (s + 1 < n_slabs) store_slab(buf ^ 1);
+      store_slab(buf ^ 1, kw, kx);
       __syncthreads();
+    };
+    load_slab(0, pwA, pxA);
+    load_slab(min(1, n_slabs - 1) * CI, pwB, pxB);
+    store_slab(0, pwA, pxA);
+    __syncthreads();
+    for (int s = 0; s < n_slabs; s += 2) {
+      slab(s, pwA, pxA, pwB, pxB);
+      if (s + 1 < n_slabs) slab(s + 1, pwB, pxB, pwA, pxA);
     }
     // add the two channel halves: waves 2, 3 hand their tiles to waves 0, 1 through LDS
-    float* red = &ws[0][0][0];
+    float* red = &ws[0][0][0];     // 2 x 16 x 64 floats fit the weight buffers
     if (khalf == 1) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) red[(thalf * 16 + r) * 64 + lane] = acc[r];
@@ -381,15 +416,49 @@ int taco_launch_embed(taco_handle h, const int64_t* const* ids_dev, const int32_
   return TACO_OK;
 }
 
+// One zero word per device in global memory: what staging loads of padding positions read.
+static float* g_conv_zero[64] = {nullptr};
+
+int taco_conv_prepare() {
+  int dev = 0;
+  TACO_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) TACO_FAIL(TACO_EINVAL, "device index %d", dev);
+  if (!g_conv_zero[dev]) {
+    TACO_HIP(hipMalloc((void**)&g_conv_zero[dev], 256));
+    TACO_HIP(hipMemset(g_conv_zero[dev], 0, 256));
+  }
+  // the slab buffers exceed the default 64 KiB of dynamic LDS for the wider kernels
+#define TACO_CONV_ATTR(KS)                                                                                      \
+  TACO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(taco_conv_kernel<KS, false>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                               (int)taco_conv_lds_bytes(KS)));                                                                  \
+  TACO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(taco_conv_kernel<KS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                               (int)taco_conv_lds_bytes(KS)));
+  TACO_CONV_ATTR(1)
+  TACO_CONV_ATTR(3)
+  TACO_CONV_ATTR(5)
+  TACO_CONV_ATTR(7)
+  TACO_CONV_ATTR(9)
+#undef TACO_CONV_ATTR
+  return TACO_OK;
+}
+
 int taco_launch_conv(const float* in, float* out, const float* w, const float* bias, const float* alpha,
                      const float* beta, const float* residual, const int32_t* lens, int B, int c_in,
                      int c_out, int k, int T, int act, int layout, hipStream_t s) {
+  int dev = 0;
+  TACO_HIP(hipGetDevice(&dev));
+  const float* zero = (dev >= 0 && dev < 64) ? g_conv_zero[dev] : nullptr;
+  if (!zero) TACO_FAIL(TACO_EINVAL, "taco_conv_prepare has not run on device %d", dev);
   const dim3 grid((T + CV_TT - 1) / CV_TT, (c_out + CV_CO - 1) / CV_CO, B);
   switch (k) {
 #define TACO_CONV_CASE(KS)                                                                          \
   case KS:                                                                                          \
-    hipLaunchKernelGGL(taco_conv_kernel<KS>, grid, dim3(256), 0, s, in, out, w, bias, alpha, beta,  \
-                       residual, lens, c_in, c_out, T, act, layout);                                    \
+    if (layout & 1)                                                                                 \
+      hipLaunchKernelGGL((taco_conv_kernel<KS, true>), grid, dim3(256), taco_conv_lds_bytes(KS), s, in, out, w, bias, alpha, beta, \
+                         residual, lens, c_in, c_out, T, act, layout, zero);                        \
+    else                                                                                            \
+    hipLaunchKernelGGL((taco_conv_kernel<KS, false>), grid, dim3(256), taco_conv_lds_bytes(KS), s, in, out, w, bias, alpha, beta,  \
+                       residual, lens, c_in, c_out, T, act, layout, zero);                              \
     break;
     TACO_CONV_CASE(1)
     TACO_CONV_CASE(3)

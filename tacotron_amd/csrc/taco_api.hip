@@ -234,11 +234,12 @@ extern "C" int taco_create(const taco_dims* dims, const taco_weights* weights, i
   TACO_CREATE_HIP(hipMalloc((void**)&h->dec_gran, taco_decoder_granules(h->n_cu) * sizeof(taco_granule)));
   h->enc_gran_count = taco_enc_lstm_granules();
   TACO_CREATE_HIP(hipMalloc((void**)&h->enc_gran, h->enc_gran_count * sizeof(taco_granule)));
-  TACO_CREATE_HIP(hipMalloc((void**)&h->dec_ctl, sizeof(taco_dec_ctl)));
+  h->dec_ctl_cap = 64;
+  TACO_CREATE_HIP(hipMalloc((void**)&h->dec_ctl, sizeof(taco_dec_ctl) * h->dec_ctl_cap));
   TACO_CREATE_HIP(hipMalloc((void**)&h->enc_ctl, 64));
   TACO_CREATE_HIP(hipMemset(h->enc_ctl, 0, 64));
   TACO_CREATE_HIP(hipHostMalloc((void**)&h->enc_ctl_host, 64, hipHostMallocDefault));
-  TACO_CREATE_HIP(hipHostMalloc((void**)&h->dec_ctl_host, sizeof(taco_dec_ctl), hipHostMallocDefault));
+  TACO_CREATE_HIP(hipHostMalloc((void**)&h->dec_ctl_host, sizeof(taco_dec_ctl) * h->dec_ctl_cap, hipHostMallocDefault));
   TACO_CREATE_HIP(hipEventCreate(&h->ev_start));
   TACO_CREATE_HIP(hipEventCreate(&h->ev_stop));
   rc = taco_decoder_prepare(h);
@@ -349,7 +350,26 @@ extern "C" int taco_decode(taco_handle h, const float* memory, const float* proc
   hipStream_t s = (hipStream_t)stream;
   const taco_dims& d = h->d;
   TACO_HIP(hipSetDevice(h->device));
-  // Utterances are independent; at this stage each one is a persistent launch of its own.
+  if (B > h->dec_ctl_cap) {
+    taco_dec_ctl *dev = nullptr, *host = nullptr;
+    const int cap = B + 64;
+    if (hipMalloc((void**)&dev, sizeof(taco_dec_ctl) * cap) != hipSuccess) TACO_FAIL(TACO_ENOMEM, "hipMalloc of %d control blocks failed", cap);
+    if (hipHostMalloc((void**)&host, sizeof(taco_dec_ctl) * cap, hipHostMallocDefault) != hipSuccess) {
+      (void)hipFree(dev);
+      TACO_FAIL(TACO_ENOMEM, "hipHostMalloc of %d control blocks failed", cap);
+    }
+    TACO_HIP(hipStreamSynchronize(s));
+    (void)hipFree(h->dec_ctl);
+    (void)hipHostFree(h->dec_ctl_host);
+    h->dec_ctl = dev; h->dec_ctl_host = host; h->dec_ctl_cap = cap;
+  }
+  // outputs start as zeros (columns at or past n_frames stay zero), control blocks cleared: once per call
+  TACO_HIP(hipMemsetAsync(h->dec_ctl, 0, sizeof(taco_dec_ctl) * (size_t)B, s));
+  TACO_HIP(hipMemsetAsync(mel, 0, sizeof(float) * (size_t)B * d.n_mel * T_cap, s));
+  TACO_HIP(hipMemsetAsync(gate, 0, sizeof(float) * (size_t)B * T_cap, s));
+  if (align) TACO_HIP(hipMemsetAsync(align, 0, sizeof(float) * (size_t)B * T_cap * T_in, s));
+  // Utterances are independent; each one is a persistent launch of its own, enqueued back to back with no
+  // host round trip in between.
   for (int b = 0; b < B; ++b) {
     const int rc = taco_launch_decoder(
         h, memory + (size_t)b * T_in * d.M, processed_memory + (size_t)b * T_in * d.A, T_in, lens, b, masks, T_cap,
@@ -358,7 +378,7 @@ extern "C" int taco_decode(taco_handle h, const float* memory, const float* proc
         n_frames + b, reached_max + b, s);
     if (rc != TACO_OK) return rc;
   }
-  return TACO_OK;
+  return taco_decoder_collect(h, B, s);
 }
 
 extern "C" int taco_postnet(taco_handle h, const float* mel, const int32_t* n_frames, int32_t B, int32_t T_cap,

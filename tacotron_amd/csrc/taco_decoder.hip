@@ -681,6 +681,10 @@ int taco_decoder_check_dims(const taco_dims& d, int n_wg) {
   return TACO_OK;
 }
 
+#ifdef TACO_STAMPS
+static unsigned long long* g_stamps_dev = nullptr;
+#endif
+
 int taco_launch_decoder(taco_handle h, const float* memory, const float* pm, int T_in, const int32_t* lens,
                         int b, const uint8_t* masks, int T_cap, int max_steps, float thr, const float* forced_mel,
                         float* mel, float* gate, float* align, int32_t* n_frames, uint8_t* reached,
@@ -701,7 +705,7 @@ int taco_launch_decoder(taco_handle h, const float* memory, const float* pm, int
   a.proj_w = w.proj_w; a.proj_b = w.proj_b; a.gate_w = w.gate_w; a.gate_b = w.gate_b;
   a.pm = pm; a.G = h->ws_G; a.masks = masks; a.T_cap = T_cap; a.max_steps = max_steps; a.thr = thr;
   a.forced_mel = forced_mel; a.mel = mel; a.gate = gate; a.align = align; a.n_frames_out = n_frames; a.reached_out = reached;
-  a.gran = h->dec_gran; a.lay = h->dec_lay; a.ctl = h->dec_ctl;
+  a.gran = h->dec_gran; a.lay = h->dec_lay; a.ctl = h->dec_ctl + b;
 
   // folded context weights of this utterance: G = ctx_w_cat [rows][M] * memory^T [M][T_in], run as a
   // kernel-size-1 convolution over the position-major memory (columns >= len come out as zero)
@@ -718,19 +722,14 @@ int taco_launch_decoder(taco_handle h, const float* memory, const float* pm, int
 
   const size_t gran_bytes = (size_t)h->dec_lay.per_parity * 2 * sizeof(taco_granule);
   TACO_HIP(hipMemsetAsync(h->dec_gran, 0, gran_bytes, s));
-  TACO_HIP(hipMemsetAsync(h->dec_ctl, 0, sizeof(taco_dec_ctl), s));
-  TACO_HIP(hipMemsetAsync(mel, 0, sizeof(float) * (size_t)d.n_mel * T_cap, s));
-  TACO_HIP(hipMemsetAsync(gate, 0, sizeof(float) * (size_t)T_cap, s));
-  if (align) TACO_HIP(hipMemsetAsync(align, 0, sizeof(float) * (size_t)T_cap * T_in, s));
 
 #ifdef TACO_STAMPS
-  static unsigned long long* stamps_dev = nullptr;
   const size_t stamp_count = (size_t)3 * TACO_STAMP_FRAMES * TACO_STAMP_POINTS;
-  if (!stamps_dev) TACO_HIP(hipMalloc((void**)&stamps_dev, stamp_count * 8));
-  TACO_HIP(hipMemsetAsync(stamps_dev, 0, stamp_count * 8, s));
-  a.stamps = stamps_dev;
+  if (!g_stamps_dev) TACO_HIP(hipMalloc((void**)&g_stamps_dev, stamp_count * 8));
+  TACO_HIP(hipMemsetAsync(g_stamps_dev, 0, stamp_count * 8, s));
+  a.stamps = g_stamps_dev;
 #endif
-  TACO_HIP(hipEventRecord(h->ev_start, s));
+  if (b == 0) TACO_HIP(hipEventRecord(h->ev_start, s));
   const bool std_geom = d.P == 256 && d.R_a == 1024 && d.R_d == 1024 && d.A == 128 && d.F == 32 && d.K == 31 &&
                         d.n_mel == 80 && n_wg == 256;
   const bool one_chunk = T_in <= TACO_CHUNK;     // all positions fit the first folded-context chunk
@@ -738,25 +737,36 @@ int taco_launch_decoder(taco_handle h, const float* memory, const float* pm, int
                        : (one_chunk ? taco_decoder_kernel<false, 1> : taco_decoder_kernel<false, 2>);
   hipLaunchKernelGGL(kern, dim3(n_wg), dim3(NT), taco_decoder_lds_bytes(), s, a);
   TACO_HIP(hipGetLastError());
+  return TACO_OK;
+}
+
+// After the last utterance of a taco_decode call has been enqueued: one wait for the whole batch, then
+// the control blocks (and what a preceding taco_encode on this stream found) are checked.
+int taco_decoder_collect(taco_handle h, int B, hipStream_t s) {
   TACO_HIP(hipEventRecord(h->ev_stop, s));
   h->timing_valid = 1;
-
-  // results: frame count and flags come back through the control block
-  TACO_HIP(hipMemcpyAsync(h->dec_ctl_host, h->dec_ctl, sizeof(taco_dec_ctl), hipMemcpyDeviceToHost, s));
+  TACO_HIP(hipMemcpyAsync(h->dec_ctl_host, h->dec_ctl, sizeof(taco_dec_ctl) * (size_t)B, hipMemcpyDeviceToHost, s));
   TACO_HIP(hipMemcpyAsync(h->enc_ctl_host, h->enc_ctl, 64, hipMemcpyDeviceToHost, s));
   TACO_HIP(hipStreamSynchronize(s));
   {
-    const int erc = taco_check_encoder_flags(h, s);     // what a preceding taco_encode on this stream found
+    const int erc = taco_check_encoder_flags(h, s);
     if (erc != TACO_OK) return erc;
   }
-  if (h->dec_ctl_host->abort_code != 0)
-    TACO_FAIL(TACO_ETIMEDOUT, "decoder hand-off wait gave up (code %u, info 0x%x) after %u frames",
-              h->dec_ctl_host->abort_code, h->dec_ctl_host->abort_info, h->dec_ctl_host->n_frames);
+  int longest = 0;
+  for (int b = 0; b < B; ++b) {
+    const taco_dec_ctl& c = h->dec_ctl_host[b];
+    if (c.abort_code != 0)
+      TACO_FAIL(TACO_ETIMEDOUT, "decoder hand-off wait gave up (utterance %d, code %u, info 0x%x) after %u frames", b,
+                c.abort_code, c.abort_info, c.n_frames);
+    if ((int)c.n_frames > longest) longest = (int)c.n_frames;
+  }
 #ifdef TACO_STAMPS
   {
+    const size_t stamp_count = (size_t)3 * TACO_STAMP_FRAMES * TACO_STAMP_POINTS;
     std::vector<unsigned long long> st(stamp_count);
-    TACO_HIP(hipMemcpy(st.data(), stamps_dev, stamp_count * 8, hipMemcpyDeviceToHost));
-    const int nfr = (int)h->dec_ctl_host->n_frames < TACO_STAMP_FRAMES ? (int)h->dec_ctl_host->n_frames : TACO_STAMP_FRAMES;
+    TACO_HIP(hipMemcpy(st.data(), g_stamps_dev, stamp_count * 8, hipMemcpyDeviceToHost));
+    const int n_last = (int)h->dec_ctl_host[B - 1].n_frames;
+    const int nfr = n_last < TACO_STAMP_FRAMES ? n_last : TACO_STAMP_FRAMES;
     static const char* names[TACO_STAMP_POINTS] = {"frame top done", "S1 + S2 (P group)", "gather p", "S3 attn LSTM",
         "gather ah", "S4 q + energy partials (Q group)", "gather energy partials", "S6 softmax",
         "S7 dec LSTM", "proj half / location term", "gather dh", "S8 proj (M group)"};
@@ -776,7 +786,7 @@ int taco_launch_decoder(taco_handle h, const float* memory, const float* pm, int
     }
   }
 #endif
-  h->last_frames = (int32_t)h->dec_ctl_host->n_frames;
+  h->last_frames = longest;
   return TACO_OK;
 }
 

@@ -101,8 +101,9 @@ struct taco_handle_s {
   size_t enc_gran_count;
   taco_granule* dec_gran;    // decoder hand-off words, 2 parities
   taco_dec_layout dec_lay;
-  taco_dec_ctl* dec_ctl;     // device
+  taco_dec_ctl* dec_ctl;     // device, one block per utterance of a taco_decode call (grow-only)
   taco_dec_ctl* dec_ctl_host;  // pinned host mirror
+  int dec_ctl_cap;
   uint32_t* enc_ctl;         // device: [0] abort code, [1] abort info of the encoder LSTM kernel, [2] 1 + channel of an
                              // out-of-range input id (speakers: 1 + TACO_MAX_CHANNELS)
   uint32_t* enc_ctl_host;    // pinned host mirror [16]
@@ -135,6 +136,7 @@ int taco_launch_decoder(taco_handle h, const float* memory, const float* pm, int
                         int b, const uint8_t* masks, int T_cap, int max_steps, float thr, const float* forced_mel,
                         float* mel, float* gate, float* align, int32_t* n_frames, uint8_t* reached,
                         hipStream_t s);
+int taco_decoder_collect(taco_handle h, int B, hipStream_t s);
 size_t taco_decoder_lds_bytes();
 size_t taco_decoder_granules(int n_wg);
 void taco_decoder_fill_layout(taco_dec_layout* lay, int n_wg);

@@ -168,6 +168,12 @@ __device__ __forceinline__ void dot_chunks(const float (*w0)[4], const float (*w
   acc[1] += (p[1][0] + p[1][1]) + (p[1][2] + p[1][3]);
 }
 
+// One register-resident chunk of two rows against four activation values held in registers.
+__device__ __forceinline__ void dot_reg(const float (&w0)[4], const float (&w1)[4], const float4 x, float (&acc)[2]) {
+  acc[0] += (fmaf(w0[0], x.x, w0[1] * x.y)) + (fmaf(w0[2], x.z, w0[3] * x.w));
+  acc[1] += (fmaf(w1[0], x.x, w1[1] * x.y)) + (fmaf(w1[2], x.z, w1[3] * x.w));
+}
+
 // Per-lane partial of the dot product of an LDS row with an LDS vector, NC chunks of 256 columns:
 // lane l takes columns 256*c + 4*l .. +3 (16-byte LDS reads, all issued before the first FMA).
 // Both arrays are zero beyond the row's true length, so no bounds are checked.
@@ -228,6 +234,7 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
   const int j = blockIdx.x;
   const int n_wg = STD ? 256 : a.n_wg;
   const int len = a.lens ? min(a.lens[a.b], a.T_in) : a.T_in;
+  const int len4 = (len + 3) & ~3;                 // stride of an energy-partial group: keeps 16-byte reads aligned
 
   for (int i = tid; i < L_TOTAL; i += NT) lds[i] = 0.0f;
   __syncthreads();
@@ -492,11 +499,13 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
       taco_lds_barrier();
       {
         const int grp = j - q_off;
-        _Pragma("unroll 1") for (int s = tid; s < len; s += NT) {
+        _Pragma("unroll 1") for (int s = tid; s < len4; s += NT) {
           float e = 0.0f;
+          if (s < len) {
 #pragma unroll
-          for (int w8 = 0; w8 < NW; ++w8) e += lds[LQ_PE8 + w8 * TACO_MAX_TIN + s];
-          taco_publish_rep<TACO_REP_PE>(g + a.lay.pe, a.lay.pe_cap, grp * len + s, ep, e);
+            for (int w8 = 0; w8 < NW; ++w8) e += lds[LQ_PE8 + w8 * TACO_MAX_TIN + s];
+          }
+          taco_publish_rep<TACO_REP_PE>(g + a.lay.pe, a.lay.pe_cap, grp * len4 + s, ep, e);
         }
       }
       taco_lds_barrier();                          // the per-wave partials' area is about to receive the gathered ones
@@ -505,66 +514,80 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
     TACO_STAMP(5);
 
     // ============ S6: energies = sum of the groups' partials; softmax over all positions (every workgroup) ============
-    taco_gather<NT>(g + a.lay.pe + (j % TACO_REP_PE) * a.lay.pe_cap, n_q_wg * len, ep, lds + L_PE, wctx, 0x700u);
+    taco_gather<NT>(g + a.lay.pe + (j % TACO_REP_PE) * a.lay.pe_cap, n_q_wg * len4, ep, lds + L_PE, wctx, 0x700u);
     TACO_STAMP(6);
+    // Every wave computes the whole softmax by itself, lane l on positions 4l..4l+3 of each chunk: the
+    // weights come out in registers in exactly the layout of the folded-context columns, so the
+    // decoder-LSTM rows are finished without a workgroup barrier or an LDS round trip in between.
+    float4 wgt[NCTX];
     {
-      constexpr int PER = TACO_MAX_TIN / NT;   // positions per thread
-      float ev[PER], ex[PER];
-      float wm = -INFINITY;
+      float4 ev[NCTX];
+      float mx = -INFINITY;
 #pragma unroll
-      for (int i = 0; i < PER; ++i) {
-        const int s = tid + i * NT;
-        ev[i] = -INFINITY;
-        if (s < len) {
-          float e = lds[L_PE + s];
-          for (int gq = 1; gq < n_q_wg; ++gq) e += lds[L_PE + gq * len + s];
-          ev[i] = e;
-        }
-        wm = fmaxf(wm, ev[i]);
+      for (int c = 0; c < NCTX; ++c) {
+        const int s0 = c * TACO_CHUNK + lane * 4;
+        float4 e = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (s0 < len4)
+          for (int gq = 0; gq < n_q_wg; ++gq) {
+            const float4 pe = *reinterpret_cast<const float4*>(lds + L_PE + gq * len4 + s0);
+            e.x += pe.x; e.y += pe.y; e.z += pe.z; e.w += pe.w;
+          }
+        e.x = s0 + 0 < len ? e.x : -INFINITY;
+        e.y = s0 + 1 < len ? e.y : -INFINITY;
+        e.z = s0 + 2 < len ? e.z : -INFINITY;
+        e.w = s0 + 3 < len ? e.w : -INFINITY;
+        ev[c] = e;
+        mx = fmaxf(mx, fmaxf(fmaxf(e.x, e.y), fmaxf(e.z, e.w)));
       }
-      wm = taco_wave_max(wm);
-      if (lane == 0) lds[L_RED + wave] = wm;
-      taco_lds_barrier();
-      float mx = lds[L_RED];
-#pragma unroll
-      for (int i = 1; i < NW; ++i) mx = fmaxf(mx, lds[L_RED + i]);
-      float ws = 0.0f;
-#pragma unroll
-      for (int i = 0; i < PER; ++i) {
-        const int s = tid + i * NT;
-        ex[i] = s < len ? taco_exp(ev[i] - mx) : 0.0f;
-        ws += ex[i];
-      }
-      ws = taco_wave_sum(ws);
-      if (lane == 0) lds[L_RED + 16 + wave] = ws;
-      taco_lds_barrier();
+      mx = taco_wave_max(mx);
       float sum = 0.0f;
 #pragma unroll
-      for (int i = 0; i < NW; ++i) sum += lds[L_RED + 16 + i];
-#pragma unroll
-      for (int i = 0; i < PER; ++i) {
-        const int s = tid + i * NT;
-        if (s < len) {
-          const float wgt = ex[i] / sum;
-          lds[L_AW + HALO + s] = wgt;
-          lds[L_CUM + HALO + s] += wgt;
-          if (j == n_wg - 1 && a.align) a.align[(size_t)t * a.T_in + s] = wgt;
-        }
+      for (int c = 0; c < NCTX; ++c) {
+        float4 x;
+        x.x = ev[c].x == -INFINITY ? 0.0f : taco_exp(ev[c].x - mx);
+        x.y = ev[c].y == -INFINITY ? 0.0f : taco_exp(ev[c].y - mx);
+        x.z = ev[c].z == -INFINITY ? 0.0f : taco_exp(ev[c].z - mx);
+        x.w = ev[c].w == -INFINITY ? 0.0f : taco_exp(ev[c].w - mx);
+        wgt[c] = x;
+        sum += (x.x + x.y) + (x.z + x.w);
       }
-      taco_lds_barrier();
+      sum = taco_wave_sum(sum);
+      const float inv = 1.0f / sum;
+#pragma unroll
+      for (int c = 0; c < NCTX; ++c) { wgt[c].x *= inv; wgt[c].y *= inv; wgt[c].z *= inv; wgt[c].w *= inv; }
     }
 
     // ============ S7: decoder LSTM; the context enters as G * w, no hand-off ============
     TACO_STAMP(7);
     const float* aw = lds + L_AW + HALO;          // this frame's attention weights, zero beyond len
     if (act_d) {
-      dot_chunks<1>(wd[0] + TACO_NA, wd[1] + TACO_NA, aw, lane, acc_d);
-      if (NCTX > 1) dot_chunks<1>(wd[0] + TACO_NA + NCTX - 1, wd[1] + TACO_NA + NCTX - 1, aw + TACO_CHUNK, lane, acc_d);
+#pragma unroll
+      for (int c = 0; c < NCTX; ++c) dot_reg(wd[0][TACO_NA + c], wd[1][TACO_NA + c], wgt[c], acc_d);
       const float s0 = taco_wave_sum(acc_d[0]);
       const float s1 = taco_wave_sum(acc_d[1]);
       if (lane == 0) {
         lds[L_GATES + wave * 2 + 0] = s0;
         lds[L_GATES + wave * 2 + 1] = s1;
+      }
+    }
+    // every wave leaves an eighth of the weights in LDS (all hold the same values) for the projection rows,
+    // the location term and the next frame's attention-LSTM partial sums, accumulates them, and the last
+    // workgroup writes the alignment row
+    if ((lane >> 3) == wave) {
+#pragma unroll
+      for (int c = 0; c < NCTX; ++c) {
+        const int s0 = c * TACO_CHUNK + lane * 4;
+        *reinterpret_cast<float4*>(lds + L_AW + HALO + s0) = wgt[c];
+        float4 cm = *reinterpret_cast<float4*>(lds + L_CUM + HALO + s0);
+        cm.x += wgt[c].x; cm.y += wgt[c].y; cm.z += wgt[c].z; cm.w += wgt[c].w;
+        *reinterpret_cast<float4*>(lds + L_CUM + HALO + s0) = cm;
+        if (j == n_wg - 1 && a.align) {
+          float* row = a.align + (size_t)t * a.T_in + s0;
+          if (s0 + 0 < len) row[0] = wgt[c].x;
+          if (s0 + 1 < len) row[1] = wgt[c].y;
+          if (s0 + 2 < len) row[2] = wgt[c].z;
+          if (s0 + 3 < len) row[3] = wgt[c].w;
+        }
       }
     }
     taco_lds_barrier();

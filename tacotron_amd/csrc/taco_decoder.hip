@@ -196,6 +196,27 @@ __device__ __forceinline__ float row_partial(const float* w_lds, const float* x_
   return (a0 + a1) + (a2 + a3);
 }
 
+// The same for two LDS rows against one LDS vector: the vector is read once.
+template <int NC>
+__device__ __forceinline__ void row_partial2(const float* w0_lds, const float* w1_lds, const float* x_lds, int lane,
+                                             float& r0, float& r1) {
+  float4 a[NC], b[NC], xv[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    a[c] = *reinterpret_cast<const float4*>(w0_lds + c * TACO_CHUNK + lane * 4);
+    b[c] = *reinterpret_cast<const float4*>(w1_lds + c * TACO_CHUNK + lane * 4);
+    xv[c] = *reinterpret_cast<const float4*>(x_lds + c * TACO_CHUNK + lane * 4);
+  }
+  float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f, q0 = 0.0f, q1 = 0.0f, q2 = 0.0f, q3 = 0.0f;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    p0 = fmaf(a[c].x, xv[c].x, p0); p1 = fmaf(a[c].y, xv[c].y, p1); p2 = fmaf(a[c].z, xv[c].z, p2); p3 = fmaf(a[c].w, xv[c].w, p3);
+    q0 = fmaf(b[c].x, xv[c].x, q0); q1 = fmaf(b[c].y, xv[c].y, q1); q2 = fmaf(b[c].z, xv[c].z, q2); q3 = fmaf(b[c].w, xv[c].w, q3);
+  }
+  r0 = (p0 + p1) + (p2 + p3);
+  r1 = (q0 + q1) + (q2 + q3);
+}
+
 // Applies the four LSTM gate non-linearities in four lanes at once and finishes the cell update:
 // lanes 4u..4u+3 of wave 0 hold gates i, f, g, o of unit u.  Returns h' in all four lanes of the unit.
 __device__ __forceinline__ float lstm_cell_lanes(const float* gates_lds, const float* bias_lds, float* cell_lds,
@@ -485,12 +506,12 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
       // wave w: query values of dimensions 2w, 2w+1, then their energy terms for every position (lane =
       // position); the 8 waves' partial sums meet in LDS
       float qv[2], vv[2];
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const int row = wave * 2 + r;
-        qv[r] = taco_wave_sum(row_partial<TACO_NA>(lds + LQ_ROWS + row * (TACO_NA * TACO_CHUNK), lds + L_XAH, lane));
-        vv[r] = lds[LQ_V + row];            // rows beyond my dimensions: zero row, v = 0, finite U
-      }
+      row_partial2<TACO_NA>(lds + LQ_ROWS + (wave * 2) * (TACO_NA * TACO_CHUNK), lds + LQ_ROWS + (wave * 2 + 1) * (TACO_NA * TACO_CHUNK),
+                            lds + L_XAH, lane, qv[0], qv[1]);
+      qv[0] = taco_wave_sum(qv[0]);
+      qv[1] = taco_wave_sum(qv[1]);
+      vv[0] = lds[LQ_V + wave * 2];           // rows beyond my dimensions: zero row, v = 0, finite U
+      vv[1] = lds[LQ_V + wave * 2 + 1];
       _Pragma("unroll 2") for (int s = lane; s < len; s += 64) {
         const float e0 = vv[0] * taco_tanh(qv[0] + lds[LQ_U + (wave * 2 + 0) * TACO_MAX_TIN + s]);
         const float e1 = vv[1] * taco_tanh(qv[1] + lds[LQ_U + (wave * 2 + 1) * TACO_MAX_TIN + s]);

@@ -142,8 +142,14 @@ constexpr int TACO_STAMP_FRAMES = 256, TACO_STAMP_POINTS = 12;
     if (tid == 0 && (j == 0 || j == 32 || j == 200) && t < TACO_STAMP_FRAMES)                           \
       a.stamps[((size_t)(j == 0 ? 0 : j == 32 ? 1 : 2) * TACO_STAMP_FRAMES + t) * TACO_STAMP_POINTS + (k)] = wall_clock64(); \
   } while (0)
+#define TACO_QSTAMP(k)                                                                                  \
+  do {                                                                                                  \
+    if (tid == 0 && j == 32 && t < TACO_STAMP_FRAMES)                                                   \
+      a.stamps[((size_t)3 * TACO_STAMP_FRAMES + t) * TACO_STAMP_POINTS + (k)] = wall_clock64();         \
+  } while (0)
 #else
 #define TACO_STAMP(k) do {} while (0)
+#define TACO_QSTAMP(k) do {} while (0)
 #endif
 
 // Dot product of NC register-resident chunks with the activation vector in LDS.  Lane l holds
@@ -503,6 +509,7 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
     else taco_gather<NT>(g + a.lay.ah + (j % TACO_REP_BIG) * a.lay.ah_cap, Ra, ep, lds + L_XAH, wctx, 0x500u);
     TACO_STAMP(4);
     if (is_q) {
+      TACO_QSTAMP(0);
       // wave w: query values of dimensions 2w, 2w+1, then their energy terms for every position (lane =
       // position); the 8 waves' partial sums meet in LDS
       float qv[2], vv[2];
@@ -512,12 +519,15 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
       qv[1] = taco_wave_sum(qv[1]);
       vv[0] = lds[LQ_V + wave * 2];           // rows beyond my dimensions: zero row, v = 0, finite U
       vv[1] = lds[LQ_V + wave * 2 + 1];
+      TACO_QSTAMP(1);
       _Pragma("unroll 2") for (int s = lane; s < len; s += 64) {
         const float e0 = vv[0] * taco_tanh(qv[0] + lds[LQ_U + (wave * 2 + 0) * TACO_MAX_TIN + s]);
         const float e1 = vv[1] * taco_tanh(qv[1] + lds[LQ_U + (wave * 2 + 1) * TACO_MAX_TIN + s]);
         lds[LQ_PE8 + wave * TACO_MAX_TIN + s] = e0 + e1;
       }
+      TACO_QSTAMP(2);
       taco_lds_barrier();
+      TACO_QSTAMP(3);
       {
         const int grp = j - q_off;
         _Pragma("unroll 1") for (int s = tid; s < len4; s += NT) {
@@ -529,7 +539,9 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
           taco_publish_rep<TACO_REP_PE>(g + a.lay.pe, a.lay.pe_cap, grp * len4 + s, ep, e);
         }
       }
+      TACO_QSTAMP(4);
       taco_lds_barrier();                          // the per-wave partials' area is about to receive the gathered ones
+      TACO_QSTAMP(5);
     }
     if (act_d) dot_chunks<TACO_NA>(wd[0], wd[1], lds + L_XAH, lane, acc_d);
     TACO_STAMP(5);
@@ -768,7 +780,7 @@ int taco_launch_decoder(taco_handle h, const float* memory, const float* pm, int
   TACO_HIP(hipMemsetAsync(h->dec_gran, 0, gran_bytes, s));
 
 #ifdef TACO_STAMPS
-  const size_t stamp_count = (size_t)3 * TACO_STAMP_FRAMES * TACO_STAMP_POINTS;
+  const size_t stamp_count = (size_t)4 * TACO_STAMP_FRAMES * TACO_STAMP_POINTS;
   if (!g_stamps_dev) TACO_HIP(hipMalloc((void**)&g_stamps_dev, stamp_count * 8));
   TACO_HIP(hipMemsetAsync(g_stamps_dev, 0, stamp_count * 8, s));
   a.stamps = g_stamps_dev;
@@ -806,7 +818,7 @@ int taco_decoder_collect(taco_handle h, int B, hipStream_t s) {
   }
 #ifdef TACO_STAMPS
   {
-    const size_t stamp_count = (size_t)3 * TACO_STAMP_FRAMES * TACO_STAMP_POINTS;
+    const size_t stamp_count = (size_t)4 * TACO_STAMP_FRAMES * TACO_STAMP_POINTS;
     std::vector<unsigned long long> st(stamp_count);
     TACO_HIP(hipMemcpy(st.data(), g_stamps_dev, stamp_count * 8, hipMemcpyDeviceToHost));
     const int n_last = (int)h->dec_ctl_host[B - 1].n_frames;
@@ -827,6 +839,17 @@ int taco_decoder_collect(taco_handle h, int B, hipStream_t s) {
       double tot = 0;
       for (int k = 1; k < TACO_STAMP_POINTS; ++k) { fprintf(stderr, "  %-32s %7.2f\n", names[k], acc[k] / cnt); tot += acc[k] / cnt; }
       fprintf(stderr, "  %-32s %7.2f\n  total %7.2f\n", "attn partial + frame top (mel / stop)", acc[TACO_STAMP_POINTS] / cnt, tot + acc[TACO_STAMP_POINTS] / cnt);
+    }
+    if (nfr > 8) {
+      static const char* qn[6] = {"", "query rows", "energy terms", "barrier", "sum + publish", "barrier"};
+      double acc[6] = {0};
+      int cnt = 0;
+      for (int t = 4; t + 1 < nfr; ++t, ++cnt) {
+        const unsigned long long* r = &st[((size_t)3 * TACO_STAMP_FRAMES + t) * TACO_STAMP_POINTS];
+        for (int k = 1; k < 6; ++k) acc[k] += (double)(r[k] - r[k - 1]) * 0.01;
+      }
+      fprintf(stderr, "[taco stamps] inside the Q group's stage (workgroup 32):\n");
+      for (int k = 1; k < 6; ++k) fprintf(stderr, "  %-32s %7.2f\n", qn[k], acc[k] / cnt);
     }
   }
 #endif

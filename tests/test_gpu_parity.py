@@ -208,6 +208,22 @@ def test_edge_cases_against_oracle(gate_table):
   assert out[0].shape[2] == n - 1 and out[4] is True
 
 
+def test_no_step_limit_stops_on_the_stop_token():
+  """max_decoder_steps = 0 means no limit (reference: src/tacotron/model.py:561-566): the stop token alone ends
+  the utterance, at the same frame as with a generous limit, and the limit flag stays clear."""
+  z, meta = load_golden("tiny")
+  gm = gpu_model(meta["scenario"], meta["gate"])
+  ids = golden_ids(z)
+  args = (dev(ids["symbols"]), dev(ids["stresses"]), None, None, dev(ids["speakers"]))
+  torch.manual_seed(meta["seed"])
+  limited = gm.inference(*args, meta["max_steps"])
+  torch.manual_seed(meta["seed"])
+  unlimited = gm.inference(*args, 0)
+  assert unlimited[0].shape[2] == meta["n_frames"] and unlimited[4] is False
+  for a, b in zip(limited[:4], unlimited[:4]):
+    assert torch.equal(a, b)
+
+
 def test_long_input_full_size_model(gate_table):
   """Default-geometry model with more than 256 input positions (two folded-context chunks, several
   position tiles per wave in the location term), against the oracle."""

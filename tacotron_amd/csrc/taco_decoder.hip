@@ -43,9 +43,11 @@
 // states of frame t+1 are out, so no word is overwritten while someone still has to read it.  Every
 // wait is bounded by a poll budget and a global abort word, so the grid always drains.
 #include "taco_device.h"
+#include <math.h>
+#include <stdlib.h>
+#include <vector>
 #ifdef TACO_STAMPS
 #include <stdio.h>
-#include <vector>
 #endif
 
 namespace {
@@ -75,8 +77,10 @@ constexpr int L_GATES = L_CUM + TACO_MAX_TIN + 2 * HALO;       // LSTM gate pre-
 constexpr int L_RED = L_GATES + 16;                            // block-reduction scratch [32]
 constexpr int L_CELLS = L_RED + 32;                            // LSTM cell states [4 + 4]
 constexpr int L_BIAS = L_CELLS + 8;                            // b_ih + b_hh of my rows [16 + 16]
-constexpr int L_GATE_IN = L_BIAS + 32;                         // stop token of the previous frame [4]
-constexpr int L_ROLE = L_GATE_IN + 4;
+constexpr int L_GATE_IN = L_BIAS + 32;                         // stop token of the previous frame, failure flag [4]
+constexpr int L_X = L_GATE_IN + 4;                             // unnormalised attention weights of this frame
+constexpr int L_ROLE = L_X + TACO_MAX_TIN;
+static_assert(TACO_MAX_TIN == NT, "the softmax takes one position per thread");
 // P group: per wave one row of the prenet: layer 1 folded into the projection [1024 hidden + 512 folded
 //          context] and its bias, the plain layer-1 row [128] (teacher forcing), the layer-2 row [256];
 //          the gathered layer-1 output [256]; keep bytes [2 parities][2 layers][256 B]
@@ -123,6 +127,7 @@ struct DecArgs {
   const uint8_t* masks;
   int T_cap, max_steps;
   float thr;
+  int shift_energies;    // 0: the energies are small enough for exp() without subtracting their maximum
   const float* forced_mel;
   float *mel, *gate, *align;
   int32_t* n_frames_out;   // this utterance's entries of the caller's result arrays
@@ -436,26 +441,12 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
   if (is_q) update_location_term();
   __syncthreads();
   for (;; ++t) {
-    // ============ frame boundary: the previous frame's stop token ============
-    if (t > 0) {
-      const taco_granule* gp = a.gran + (size_t)((t - 1) & 1) * a.lay.per_parity;
-      const unsigned ep_prev = (unsigned)t;
-      const taco_granule* melv = gp + a.lay.mel + (j % TACO_REP_SMALL) * a.lay.mel_cap;
-      // One thread fetches the stop token.  (The P group deliberately does not poll for its layer-1 vector
-      // here as well, although both were published together: 32 x 256 early pollers on those lines delay
-      // the stores they are waiting for by more than the second round trip costs.)
-      if (tid == NT - 1) lds[L_GATE_IN] = taco_wait_one(melv, NMEL, ep_prev, wctx, 0x100u);
-      if (__syncthreads_or(wctx.failed)) break;
-      if (!forced && taco_sigmoid(lds[L_GATE_IN]) > a.thr) { stopped = 1; break; }
-    }
-    if (t == a.max_steps) break;
-    TACO_STAMP(0);
-    // Q group: this frame's location term from the previous frame's weights, while the P group works
-    if (is_q && t > 0) update_location_term();
-
     const unsigned ep = (unsigned)t + 1u;
     taco_granule* g = a.gran + (size_t)(t & 1) * a.lay.per_parity;
-    if (is_p) {
+    // P group first: prenet layer 2 of this frame heads the frame's chain of hand-offs, so it does not
+    // wait for the stop test.  Should the utterance turn out to have ended, the published values are
+    // never read (their slots are cleared before the next launch).
+    if (is_p && t < a.max_steps) {
       const unsigned char* keep_now = keep_lds + (t & 1) * 512;
       if (wave == NW - 1 && t + 1 < a.max_steps && lane * 4 < P) {
         // next frame's keep bytes, fetched a frame ahead (a first-touch line comes from HBM)
@@ -476,6 +467,24 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
         taco_publish_lanes<TACO_REP_SMALL>(g + a.lay.p, a.lay.p_cap, p_row, ep, v, lane);
       }
     }
+    // ============ frame boundary: the previous frame's stop token ============
+    if (t > 0) {
+      const taco_granule* gp = a.gran + (size_t)((t - 1) & 1) * a.lay.per_parity;
+      const unsigned ep_prev = (unsigned)t;
+      const taco_granule* melv = gp + a.lay.mel + (j % TACO_REP_SMALL) * a.lay.mel_cap;
+      // One thread fetches the stop token.  (The P group does not poll for its layer-1 vector together
+      // with it, although both are published at the same time: 32 x 256 early pollers on those lines delay
+      // the stores they are waiting for by more than the second round trip costs.)
+      if (tid == NT - 1) lds[L_GATE_IN] = taco_wait_one(melv, NMEL, ep_prev, wctx, 0x100u);
+      if (wctx.failed) lds[L_GATE_IN + 1] = 1.0f;
+      taco_lds_barrier();
+      if (lds[L_GATE_IN + 1] != 0.0f) break;
+      if (!forced && taco_sigmoid(lds[L_GATE_IN]) > a.thr) { stopped = 1; break; }
+    }
+    if (t == a.max_steps) break;
+    TACO_STAMP(0);
+    // Q group: this frame's location term from the previous frame's weights, while the P group works
+    if (is_q && t > 0) update_location_term();
     TACO_STAMP(1);
 
     // ============ S3: attention LSTM ============
@@ -549,45 +558,40 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
     // ============ S6: energies = sum of the groups' partials; softmax over all positions (every workgroup) ============
     taco_gather<NT>(g + a.lay.pe + (j % TACO_REP_PE) * a.lay.pe_cap, n_q_wg * len4, ep, lds + L_PE, wctx, 0x700u);
     TACO_STAMP(6);
-    // Every wave computes the whole softmax by itself, lane l on positions 4l..4l+3 of each chunk: the
-    // weights come out in registers in exactly the layout of the folded-context columns, so the
-    // decoder-LSTM rows are finished without a workgroup barrier or an LDS round trip in between.
+    // One position per thread: the energy is the sum of the groups' partials; exp() without a shift where
+    // the energies are known to be small (softmax does not depend on the shift: it only guards the range),
+    // else shifted by their maximum, which costs one more exchange through LDS.  The waves' partial sums and
+    // the unnormalised weights meet in LDS; then every wave picks the weights up in the layout of its
+    // folded-context columns (lane l: positions 4l..4l+3 of each chunk) and normalises them in registers.
     float4 wgt[NCTX];
+    float w_own;
     {
-      float4 ev[NCTX];
-      float mx = -INFINITY;
+      float e = 0.0f;
+      if (tid < len)
+        for (int gq = 0; gq < n_q_wg; ++gq) e += lds[L_PE + gq * len4 + tid];
+      float mx = 0.0f;
+      if (a.shift_energies) {
+        const float m = taco_wave_max(tid < len ? e : -INFINITY);
+        if (lane == 0) lds[L_RED + 8 + wave] = m;
+        taco_lds_barrier();
+        const float4 m0 = *reinterpret_cast<const float4*>(lds + L_RED + 8);
+        const float4 m1 = *reinterpret_cast<const float4*>(lds + L_RED + 12);
+        mx = fmaxf(fmaxf(fmaxf(m0.x, m0.y), fmaxf(m0.z, m0.w)), fmaxf(fmaxf(m1.x, m1.y), fmaxf(m1.z, m1.w)));
+      }
+      const float x = tid < len ? taco_exp(e - mx) : 0.0f;
+      lds[L_X + tid] = x;
+      const float part = taco_wave_sum(x);
+      if (lane == 0) lds[L_RED + wave] = part;
+      taco_lds_barrier();
+      const float4 s0 = *reinterpret_cast<const float4*>(lds + L_RED);
+      const float4 s1 = *reinterpret_cast<const float4*>(lds + L_RED + 4);
+      const float inv = 1.0f / (((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w)));
 #pragma unroll
       for (int c = 0; c < NCTX; ++c) {
-        const int s0 = c * TACO_CHUNK + lane * 4;
-        float4 e = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (s0 < len4)
-          for (int gq = 0; gq < n_q_wg; ++gq) {
-            const float4 pe = *reinterpret_cast<const float4*>(lds + L_PE + gq * len4 + s0);
-            e.x += pe.x; e.y += pe.y; e.z += pe.z; e.w += pe.w;
-          }
-        e.x = s0 + 0 < len ? e.x : -INFINITY;
-        e.y = s0 + 1 < len ? e.y : -INFINITY;
-        e.z = s0 + 2 < len ? e.z : -INFINITY;
-        e.w = s0 + 3 < len ? e.w : -INFINITY;
-        ev[c] = e;
-        mx = fmaxf(mx, fmaxf(fmaxf(e.x, e.y), fmaxf(e.z, e.w)));
+        const float4 xv = *reinterpret_cast<const float4*>(lds + L_X + c * TACO_CHUNK + lane * 4);
+        wgt[c] = make_float4(xv.x * inv, xv.y * inv, xv.z * inv, xv.w * inv);
       }
-      mx = taco_wave_max(mx);
-      float sum = 0.0f;
-#pragma unroll
-      for (int c = 0; c < NCTX; ++c) {
-        float4 x;
-        x.x = ev[c].x == -INFINITY ? 0.0f : taco_exp(ev[c].x - mx);
-        x.y = ev[c].y == -INFINITY ? 0.0f : taco_exp(ev[c].y - mx);
-        x.z = ev[c].z == -INFINITY ? 0.0f : taco_exp(ev[c].z - mx);
-        x.w = ev[c].w == -INFINITY ? 0.0f : taco_exp(ev[c].w - mx);
-        wgt[c] = x;
-        sum += (x.x + x.y) + (x.z + x.w);
-      }
-      sum = taco_wave_sum(sum);
-      const float inv = 1.0f / sum;
-#pragma unroll
-      for (int c = 0; c < NCTX; ++c) { wgt[c].x *= inv; wgt[c].y *= inv; wgt[c].z *= inv; wgt[c].w *= inv; }
+      w_own = x * inv;
     }
 
     // ============ S7: decoder LSTM; the context enters as G * w, no hand-off ============
@@ -603,25 +607,12 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
         lds[L_GATES + wave * 2 + 1] = s1;
       }
     }
-    // every wave leaves an eighth of the weights in LDS (all hold the same values) for the projection rows,
-    // the location term and the next frame's attention-LSTM partial sums, accumulates them, and the last
-    // workgroup writes the alignment row
-    if ((lane >> 3) == wave) {
-#pragma unroll
-      for (int c = 0; c < NCTX; ++c) {
-        const int s0 = c * TACO_CHUNK + lane * 4;
-        *reinterpret_cast<float4*>(lds + L_AW + HALO + s0) = wgt[c];
-        float4 cm = *reinterpret_cast<float4*>(lds + L_CUM + HALO + s0);
-        cm.x += wgt[c].x; cm.y += wgt[c].y; cm.z += wgt[c].z; cm.w += wgt[c].w;
-        *reinterpret_cast<float4*>(lds + L_CUM + HALO + s0) = cm;
-        if (j == n_wg - 1 && a.align) {
-          float* row = a.align + (size_t)t * a.T_in + s0;
-          if (s0 + 0 < len) row[0] = wgt[c].x;
-          if (s0 + 1 < len) row[1] = wgt[c].y;
-          if (s0 + 2 < len) row[2] = wgt[c].z;
-          if (s0 + 3 < len) row[3] = wgt[c].w;
-        }
-      }
+    // each thread leaves its position's weight in LDS for the projection rows, the location term and the
+    // next frame's attention-LSTM partial sums, accumulates it, and the last workgroup writes the alignment row
+    lds[L_AW + HALO + tid] = w_own;
+    if (tid < len) {
+      lds[L_CUM + HALO + tid] += w_own;
+      if (j == n_wg - 1 && a.align) a.align[(size_t)t * a.T_in + tid] = w_own;
     }
     taco_lds_barrier();
     if (wave == 0) {
@@ -760,6 +751,7 @@ int taco_launch_decoder(taco_handle h, const float* memory, const float* pm, int
   a.dec_w_ih = w.dec_w_ih; a.dec_w_hh = w.dec_w_hh; a.dec_b_ih = w.dec_b_ih; a.dec_b_hh = w.dec_b_hh;
   a.proj_w = w.proj_w; a.proj_b = w.proj_b; a.gate_w = w.gate_w; a.gate_b = w.gate_b;
   a.pm = pm; a.G = h->ws_G; a.masks = masks; a.T_cap = T_cap; a.max_steps = max_steps; a.thr = thr;
+  a.shift_energies = h->energy_bound > 64.0f ? 1 : 0;
   a.forced_mel = forced_mel; a.mel = mel; a.gate = gate; a.align = align; a.n_frames_out = n_frames; a.reached_out = reached;
   a.gran = h->dec_gran; a.lay = h->dec_lay; a.ctl = h->dec_ctl + b;
 
@@ -870,6 +862,15 @@ int taco_decoder_prepare(taco_handle h) {
     TACO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, NT, taco_decoder_lds_bytes()));
     if (per_cu < 1) TACO_FAIL(TACO_EINVAL, "decoder kernel does not fit on a CU (occupancy query returned %d)", per_cu);
   }
-  (void)h;
+  // |energy| <= sum_a |v_a| (each term is v_a * tanh(.)): up to 64 the softmax needs no shift by the maximum
+  // (exp stays within 1.6e-28 .. 6.3e27, normal numbers, and a sum over 512 positions is far from overflow).
+  // TACO_SOFTMAX_SHIFT=1 in the environment forces the shifted form (for timing it).
+  std::vector<float> v((size_t)h->d.A);
+  TACO_HIP(hipMemcpy(v.data(), h->w.v_w, sizeof(float) * v.size(), hipMemcpyDeviceToHost));
+  double bound = 0.0;
+  for (float x : v) bound += fabs((double)x);
+  h->energy_bound = bound == bound ? (float)bound : INFINITY;     // NaN weights: take the guarded path
+  const char* force = getenv("TACO_SOFTMAX_SHIFT");
+  if (force && force[0] == '1') h->energy_bound = INFINITY;
   return TACO_OK;
 }

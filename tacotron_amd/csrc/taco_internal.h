@@ -110,6 +110,7 @@ struct taco_handle_s {
   hipEvent_t ev_start, ev_stop;
   int last_frames;
   int timing_valid;
+  float energy_bound;        // sum |v_a|: no attention energy can exceed it in magnitude
 };
 
 // ---- launchers implemented in the kernel translation units ----------------------------------

@@ -208,6 +208,38 @@ def test_edge_cases_against_oracle(gate_table):
   assert out[0].shape[2] == n - 1 and out[4] is True
 
 
+def test_large_attention_energies_are_shifted_before_exp(gate_table):
+  """A model whose energy vector v is large (sum |v| far above what exp() takes unshifted) must run the
+  softmax shifted by the maximum energy, as the reference's softmax does internally: peaked but finite
+  weights that agree with the oracle.  (Energies up to +-120 overflow exp() if the shift were left out;
+  rounding differences in them are magnified by the same factor, hence the free-running tolerance.)"""
+  import copy
+  from oracle.oracle import OracleModel
+  from tacotron_amd.model import Tacotron2
+  gate = gate_table["tiny"]
+  ck = copy.deepcopy(scenario_checkpoint("tiny", gate))
+  key = "decoder.attention_layer.v.linear_layer.weight"
+  v = ck["model_state"][key]
+  ck["model_state"][key] = v * (120.0 / float(v.abs().sum()))
+  om = OracleModel(ck)
+  hp = ckpt_mod.get_hparams(ck)
+  gm = Tacotron2(hp, **abi.mapping_counts(ck, hp))
+  gm.load_state_dict(ck["model_state"])
+  gm = gm.to("cuda:0").eval()
+  for T_in, max_steps in ((37, 12), (300, 6)):
+    ids = scenarios.random_ids(ck, [T_in], seed=70 + T_in)
+    masks = prenet_keep_masks(5, max_steps, om.dims.P)
+    mem_o, pm_o = om.encode(chans(ids), ids["speakers"], None)
+    mel_o, gate_o, align_o, _, _, _ = om.decode(mem_o, pm_o, None, masks.numpy(), max_steps, gate_threshold=2.0)
+    # teacher forcing with the oracle's own frames keeps the comparison frame by frame
+    mel, gate_g, align, nf, _ = gm.decode(dev(mem_o), dev(pm_o), None, masks, max_steps, gate_threshold=2.0,
+                                          forced_mel=dev(mel_o))
+    assert int(nf[0]) == max_steps and bool(torch.isfinite(align).all())
+    assert float(align_o[0].max()) > 0.2, "the scaled energies should make the weights peaked"
+    np.testing.assert_allclose(align[0].cpu().numpy(), align_o[0], atol=FREE_TOL, rtol=0)
+    np.testing.assert_allclose(mel[0].cpu().numpy(), mel_o[0], atol=FREE_TOL, rtol=0)
+
+
 def test_no_step_limit_stops_on_the_stop_token():
   """max_decoder_steps = 0 means no limit (reference: src/tacotron/model.py:561-566): the stop token alone ends
   the utterance, at the same frame as with a generous limit, and the limit flag stays clear."""

@@ -387,6 +387,11 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
   taco_wait_ctx wctx;
   wctx.abort_word = (taco_gu32*)&a.ctl->abort_code;
   wctx.failed = 0;
+  wctx.spun = 0;
+  // this wave's naps before it polls for the prenet output, the energy partials, the decoder hidden state and
+  // (P group) the layer-1 output.  Measured one by one: each of these shortens the frame, 1.1 us together; a nap
+  // before the attention hidden state (Q group) or the stop token does not.
+  int nap_p = 0, nap_pe = 0, nap_dh = 0, nap_h1 = 0;
 
   const bool forced = a.forced_mel != nullptr;
   const int pad = (K - 1) / 2;
@@ -459,7 +464,7 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
       }
       // ---- prenet layer 2, one row per wave, on the layer-1 output the P group exchanged (all zero for
       //      frame 0: the go frame is zero and the layers have no bias) ----
-      if (t > 0) taco_gather<NT>(g + a.lay.h1 + (j % TACO_REP_SMALL) * a.lay.h1_cap, P, ep, lds + LP_H1, wctx, 0x300u);
+      if (t > 0) taco_gather<NT>(g + a.lay.h1 + (j % TACO_REP_SMALL) * a.lay.h1_cap, P, ep, lds + LP_H1, wctx, 0x300u, nap_h1);
       if (own_p) {
         float v = taco_wave_sum(row_partial<TACO_NP>(lds + LP_W2 + wave * PW, lds + LP_H1, lane));
         v = v > 0.0f ? v : 0.0f;
@@ -488,7 +493,7 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
     TACO_STAMP(1);
 
     // ============ S3: attention LSTM ============
-    taco_gather<NT>(g + a.lay.p + (j % TACO_REP_SMALL) * a.lay.p_cap, P, ep, lds + L_XP, wctx, 0x400u);
+    taco_gather<NT>(g + a.lay.p + (j % TACO_REP_SMALL) * a.lay.p_cap, P, ep, lds + L_XP, wctx, 0x400u, nap_p);
     TACO_STAMP(2);
     if (act_a) {
       dot_chunks<TACO_NP>(wa[0], wa[1], lds + L_XP, lane, acc_a);
@@ -556,7 +561,7 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
     TACO_STAMP(5);
 
     // ============ S6: energies = sum of the groups' partials; softmax over all positions (every workgroup) ============
-    taco_gather<NT>(g + a.lay.pe + (j % TACO_REP_PE) * a.lay.pe_cap, n_q_wg * len4, ep, lds + L_PE, wctx, 0x700u);
+    taco_gather<NT>(g + a.lay.pe + (j % TACO_REP_PE) * a.lay.pe_cap, n_q_wg * len4, ep, lds + L_PE, wctx, 0x700u, nap_pe);
     TACO_STAMP(6);
     // One position per thread: the energy is the sum of the groups' partials; exp() without a shift where
     // the energies are known to be small (softmax does not depend on the shift: it only guards the range),
@@ -629,8 +634,8 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
 
     // ============ S8: mel / stop-token projection rows (M group), next frame's prenet layer 1 (P group) ============
     if (is_p) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // next frame's keep bytes (LDS-DMA) have landed
-    if (!is_p && !is_m) taco_gather_late<NT>(g + a.lay.dh + (j % TACO_REP_BIG) * a.lay.dh_cap, Rd, ep, lds + L_XDH, wctx, 0x900u);
-    else taco_gather<NT>(g + a.lay.dh + (j % TACO_REP_BIG) * a.lay.dh_cap, Rd, ep, lds + L_XDH, wctx, 0x900u);
+    if (!is_p && !is_m) taco_gather_late<NT>(g + a.lay.dh + (j % TACO_REP_BIG) * a.lay.dh_cap, Rd, ep, lds + L_XDH, wctx, 0x900u, nap_dh);
+    else taco_gather<NT>(g + a.lay.dh + (j % TACO_REP_BIG) * a.lay.dh_cap, Rd, ep, lds + L_XDH, wctx, 0x900u, nap_dh);
     TACO_STAMP(10);
     if (own_m) {
       acc_p += row_partial<TACO_ND>(my_proj, lds + L_XDH, lane);

@@ -142,6 +142,7 @@ __device__ __forceinline__ void taco_publish_lanes(taco_granule* base, int cap, 
 struct taco_wait_ctx {
   taco_gu32* abort_word;     // global abort flag
   int failed;                // sticky, per thread
+  int spun;                  // set when a wait found its granule not there yet
 };
 
 // A wait gives up after this many polls (each poll is a round trip to memory of roughly a
@@ -156,6 +157,7 @@ __device__ __forceinline__ float taco_wait_one(const taco_granule* base, int idx
   taco_granule word = __hip_atomic_load(g, TACO_RLX_AGENT);
   unsigned spins = 0;
   while ((unsigned)(word >> 32) != epoch) {
+    ctx.spun = 1;
     if (ctx.failed) break;
     __builtin_amdgcn_s_sleep(TACO_POLL_SLEEP);
     if ((++spins & 255u) == 0u) {
@@ -181,11 +183,41 @@ __device__ __forceinline__ void taco_lds_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// Naps.  A poll that reaches memory just before the value does costs a whole further round trip, and
+// polls on a line that is still being written delay the write itself.  The frames of an utterance repeat
+// with nearly the same timing, so each wave keeps, per hand-off, the time it stays away from memory before
+// its first poll (in units of s_sleep 1, about 64 clocks) and steers it by what that poll finds: value
+// not there yet - nap longer next frame, by TACO_NAP_UP; there at once - shorter, by TACO_NAP_DOWN.
+#ifndef TACO_NAP_UP
+#define TACO_NAP_UP 6
+#endif
+#ifndef TACO_NAP_DOWN
+#define TACO_NAP_DOWN 1
+#endif
+constexpr int TACO_NAP_MAX = 120;      // about 3.5 us
+__device__ __forceinline__ void taco_nap(int n) {
+  for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
+}
+__device__ __forceinline__ int taco_nap_adjust(int n, int spun) {
+  const bool any = __builtin_amdgcn_readfirstlane(__any(spun) ? 1 : 0) != 0;
+  return any ? min(n + TACO_NAP_UP, TACO_NAP_MAX) : max(n - TACO_NAP_DOWN, 0);
+}
+
 // All threads of the workgroup collect granules [0, n) into LDS and synchronise.
 template <int NTHREADS>
 __device__ __forceinline__ void taco_gather(const taco_granule* base, int n, unsigned epoch, float* lds_dst,
                                             taco_wait_ctx& ctx, unsigned info) {
   for (int idx = threadIdx.x; idx < n; idx += NTHREADS) lds_dst[idx] = taco_wait_one(base, idx, epoch, ctx, info);
+  taco_lds_barrier();
+}
+// The same after this wave's nap for the hand-off, which is adjusted by what the polls found.
+template <int NTHREADS>
+__device__ __forceinline__ void taco_gather(const taco_granule* base, int n, unsigned epoch, float* lds_dst,
+                                            taco_wait_ctx& ctx, unsigned info, int& nap) {
+  taco_nap(nap);
+  ctx.spun = 0;
+  for (int idx = threadIdx.x; idx < n; idx += NTHREADS) lds_dst[idx] = taco_wait_one(base, idx, epoch, ctx, info);
+  nap = taco_nap_adjust(nap, ctx.spun);
   taco_lds_barrier();
 }
 
@@ -196,6 +228,21 @@ template <int NTHREADS>
 __device__ __forceinline__ void taco_gather_late(const taco_granule* base, int n, unsigned epoch, float* lds_dst,
                                                  taco_wait_ctx& ctx, unsigned info) {
   if (threadIdx.x < 64 && (int)threadIdx.x < n) lds_dst[threadIdx.x] = taco_wait_one(base, threadIdx.x, epoch, ctx, info);
+  taco_lds_barrier();
+  for (int idx = threadIdx.x; idx < n; idx += NTHREADS)
+    if (idx >= 64) lds_dst[idx] = taco_wait_one(base, idx, epoch, ctx, info);
+  taco_lds_barrier();
+}
+// The same with the watching wave's nap.
+template <int NTHREADS>
+__device__ __forceinline__ void taco_gather_late(const taco_granule* base, int n, unsigned epoch, float* lds_dst,
+                                                 taco_wait_ctx& ctx, unsigned info, int& nap) {
+  if (threadIdx.x < 64) {
+    taco_nap(nap);
+    ctx.spun = 0;
+    if ((int)threadIdx.x < n) lds_dst[threadIdx.x] = taco_wait_one(base, threadIdx.x, epoch, ctx, info);
+    nap = taco_nap_adjust(nap, ctx.spun);
+  }
   taco_lds_barrier();
   for (int idx = threadIdx.x; idx < n; idx += NTHREADS)
     if (idx >= 64) lds_dst[idx] = taco_wait_one(base, idx, epoch, ctx, info);

@@ -389,7 +389,7 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
   wctx.failed = 0;
   wctx.spun = 0;
   // this wave's naps before it polls for the prenet output, the energy partials, the decoder hidden state and
-  // (P group) the layer-1 output.  Measured one by one: each of these shortens the frame, 1.1 us together; a nap
+  // (P group) the layer-1 output.  Measured one by one: each of these shortens the frame, 1.5 us together; a nap
   // before the attention hidden state (Q group) or the stop token does not.
   int nap_p = 0, nap_pe = 0, nap_dh = 0, nap_h1 = 0;
 
@@ -419,12 +419,13 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
       lds[LQ_E + i] = (ck < 2 * K && (l & 15) < q_cnt) ? a.loc_fold[(size_t)dim * 2 * K + ck] : 0.0f;
     }
   }
+  constexpr int LOC_UNROLL = (STD && NCTX == 1) ? LOC_KSTEPS : 2;   // as far as the instance's registers allow without spilling
   auto update_location_term = [&]() {
     const int col = lane & 15, kq = lane >> 4;
     _Pragma("unroll 1") for (int s0 = wave * 16; s0 < len; s0 += NW * 16) {
       const int s = s0 + col;
       taco_f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll 2
+#pragma unroll LOC_UNROLL
       for (int m = 0; m < LOC_KSTEPS; ++m) {
         int ck = 4 * m + kq;
         ck = ck < 2 * K ? ck : 0;                  // taps beyond 2K meet a zero in A; any valid address will do

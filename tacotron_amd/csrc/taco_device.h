@@ -186,17 +186,19 @@ __device__ __forceinline__ void taco_lds_barrier() {
 // Naps.  A poll that reaches memory just before the value does costs a whole further round trip, and
 // polls on a line that is still being written delay the write itself.  The frames of an utterance repeat
 // with nearly the same timing, so each wave keeps, per hand-off, the time it stays away from memory before
-// its first poll (in units of s_sleep 1, about 64 clocks) and steers it by what that poll finds: value
-// not there yet - nap longer next frame, by TACO_NAP_UP; there at once - shorter, by TACO_NAP_DOWN.
+// its first poll and steers it by what the polls find: a value not there yet - nap longer next frame, by
+// TACO_NAP_UP; all there at once - shorter, by TACO_NAP_DOWN.  The nap is kept in quarters of its unit,
+// one s_sleep 1 (about 64 clocks); up / down = 16 : 1 keeps it near the late end of the arrival times
+// (measured best among 4:1 .. 32:1).
 #ifndef TACO_NAP_UP
-#define TACO_NAP_UP 6
+#define TACO_NAP_UP 16
 #endif
 #ifndef TACO_NAP_DOWN
 #define TACO_NAP_DOWN 1
 #endif
-constexpr int TACO_NAP_MAX = 120;      // about 3.5 us
+constexpr int TACO_NAP_MAX = 4 * 120;      // about 3.5 us
 __device__ __forceinline__ void taco_nap(int n) {
-  for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
+  for (int i = n >> 2; i > 0; --i) __builtin_amdgcn_s_sleep(1);
 }
 __device__ __forceinline__ int taco_nap_adjust(int n, int spun) {
   const bool any = __builtin_amdgcn_readfirstlane(__any(spun) ? 1 : 0) != 0;

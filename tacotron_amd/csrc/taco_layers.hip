@@ -273,6 +273,7 @@ __global__ __launch_bounds__(1024) void taco_enc_lstm_kernel(const EncLstmArgs a
   taco_wait_ctx wctx;
   wctx.abort_word = (taco_gu32*)a.ctl;
   wctx.failed = 0;
+  wctx.spun = 0;
   taco_granule* gdir = a.gran + (size_t)dir * EL_GRAN_DIR;
   const float* gx = a.gx + (size_t)dir * 4 * a.H * a.T;
   const bool gate_lane = active && part == 0;      // finishes its row's gate

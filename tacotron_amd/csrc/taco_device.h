@@ -205,6 +205,23 @@ __device__ __forceinline__ int taco_nap_adjust(int n, int spun) {
   return any ? min(n + TACO_NAP_UP, TACO_NAP_MAX) : max(n - TACO_NAP_DOWN, 0);
 }
 
+// Granules [0, n) into LDS, two per thread at a time with both first polls in flight together: a thread's
+// second granule does not wait for the round trip of its first.
+template <int NTHREADS>
+__device__ __forceinline__ void taco_collect(const taco_granule* base, int n, unsigned epoch, float* lds_dst,
+                                             taco_wait_ctx& ctx, unsigned info) {
+  for (int i0 = threadIdx.x; i0 < n; i0 += 2 * NTHREADS) {
+    const int i1 = i0 + NTHREADS;
+    const taco_ggran* g = (const taco_ggran*)base;
+    const taco_granule w0 = __hip_atomic_load(g + i0, TACO_RLX_AGENT);
+    const taco_granule w1 = i1 < n ? __hip_atomic_load(g + i1, TACO_RLX_AGENT) : 0;
+    const bool ok0 = (unsigned)(w0 >> 32) == epoch, ok1 = i1 >= n || (unsigned)(w1 >> 32) == epoch;
+    if (!ok0 || !ok1) ctx.spun = 1;
+    lds_dst[i0] = ok0 ? __uint_as_float((unsigned)w0) : taco_wait_one(base, i0, epoch, ctx, info);
+    if (i1 < n) lds_dst[i1] = ok1 ? __uint_as_float((unsigned)w1) : taco_wait_one(base, i1, epoch, ctx, info);
+  }
+}
+
 // All threads of the workgroup collect granules [0, n) into LDS and synchronise.
 template <int NTHREADS>
 __device__ __forceinline__ void taco_gather(const taco_granule* base, int n, unsigned epoch, float* lds_dst,
@@ -218,7 +235,7 @@ __device__ __forceinline__ void taco_gather(const taco_granule* base, int n, uns
                                             taco_wait_ctx& ctx, unsigned info, int& nap) {
   taco_nap(nap);
   ctx.spun = 0;
-  for (int idx = threadIdx.x; idx < n; idx += NTHREADS) lds_dst[idx] = taco_wait_one(base, idx, epoch, ctx, info);
+  taco_collect<NTHREADS>(base, n, epoch, lds_dst, ctx, info);
   nap = taco_nap_adjust(nap, ctx.spun);
   taco_lds_barrier();
 }

@@ -152,7 +152,13 @@ constexpr int TACO_STAMP_FRAMES = 256, TACO_STAMP_POINTS = 12;
     if (tid == 0 && j == 32 && t < TACO_STAMP_FRAMES)                                                   \
       a.stamps[((size_t)3 * TACO_STAMP_FRAMES + t) * TACO_STAMP_POINTS + (k)] = wall_clock64();         \
   } while (0)
+#define TACO_PSTAMP(k)                                                                                  \
+  do {                                                                                                  \
+    if (tid == 0 && j == 0 && t < TACO_STAMP_FRAMES)                                                    \
+      a.stamps[((size_t)3 * TACO_STAMP_FRAMES + t) * TACO_STAMP_POINTS + 6 + (k)] = wall_clock64();     \
+  } while (0)
 #else
+#define TACO_PSTAMP(k) do {} while (0)
 #define TACO_STAMP(k) do {} while (0)
 #define TACO_QSTAMP(k) do {} while (0)
 #endif
@@ -400,8 +406,7 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
   // attention-LSTM partial sums over [folded context | previous hidden]: computed at the end of
   // each frame for the next one, in the shadow of the frame-output hand-off (zero before frame 0)
   float acc_a[2] = {0.0f, 0.0f};
-  // Prenet keep bytes travel global -> LDS by LDS-DMA one frame ahead (no registers held across the
-  // frame); frame 0's are loaded here.  Only the P group uses them.
+  // Prenet keep bytes are fetched one frame ahead; frame 0's are loaded here.  Only the P group uses them.
   unsigned char* keep_lds = reinterpret_cast<unsigned char*>(lds + LP_KEEP);
   if (is_p) {
     for (int k = tid; k < 2 * P; k += NT) keep_lds[(k / P) * 256 + (k % P)] = a.masks[k];
@@ -452,26 +457,45 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
     // P group first: prenet layer 2 of this frame heads the frame's chain of hand-offs, so it does not
     // wait for the stop test.  Should the utterance turn out to have ended, the published values are
     // never read (their slots are cleared before the next launch).
+    int stop_known = 0;
+    taco_sent p_sent = {nullptr, 0};      // what this wave publishes as prenet output, and where (P group)
+    TACO_PSTAMP(0);
     if (is_p && t < a.max_steps) {
+      // the poll for the previous frame's stop token travels while the group works: issued here (by every thread,
+      // one address), looked at right after the gather below, with whose polls it has returned
+      taco_granule stop_early = 0;
+      if (t > 0)
+        stop_early = __hip_atomic_load((const taco_ggran*)(a.gran + (size_t)((t - 1) & 1) * a.lay.per_parity + a.lay.mel +
+                                                            (j % TACO_REP_SMALL) * a.lay.mel_cap) + NMEL, TACO_RLX_AGENT);
       const unsigned char* keep_now = keep_lds + (t & 1) * 512;
-      if (wave == NW - 1 && t + 1 < a.max_steps && lane * 4 < P) {
-        // next frame's keep bytes, fetched a frame ahead (a first-touch line comes from HBM)
-        const unsigned char* src = a.masks + (size_t)(t + 1) * 2 * P + lane * 4;
-        float* dst = lds + LP_KEEP + ((t + 1) & 1) * 128;
-        typedef const __attribute__((address_space(1))) void* gptr_t;
-        typedef __attribute__((address_space(3))) void* lptr_t;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 4, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t)(src + P), (lptr_t)(dst + 64), 4, 0, 0);
-      }
+      // next frame's keep bytes, fetched a frame ahead (a first-touch line comes from HBM): loaded here, stored to
+      // LDS after the gather below, by when they have arrived.  No branch around either (every wave fetches and
+      // stores the same words, clamped to valid ones), so that the compiler sees them waited for on every path
+      // and has no reason to wait for ALL outstanding memory operations later, with the publish on its way.
+      const int keep_lane = min(lane * 4, P - 4);
+      const unsigned char* keep_src = a.masks + (size_t)min(t + 1, a.max_steps - 1) * 2 * P + keep_lane;
+      const unsigned keep_next0 = *reinterpret_cast<const unsigned*>(keep_src);
+      const unsigned keep_next1 = *reinterpret_cast<const unsigned*>(keep_src + P);
       // ---- prenet layer 2, one row per wave, on the layer-1 output the P group exchanged (all zero for
       //      frame 0: the go frame is zero and the layers have no bias) ----
       if (t > 0) taco_gather<NT>(g + a.lay.h1 + (j % TACO_REP_SMALL) * a.lay.h1_cap, P, ep, lds + LP_H1, wctx, 0x300u, nap_h1);
+      TACO_PSTAMP(1);
+      {
+        unsigned* dst = reinterpret_cast<unsigned*>(lds + LP_KEEP + ((t + 1) & 1) * 128);
+        dst[keep_lane >> 2] = keep_next0;
+        dst[64 + (keep_lane >> 2)] = keep_next1;
+      }
+      // (looked at before the publish below: a wait for a load that follows a store also waits for the store
+      // to be acknowledged)
+      stop_known = t > 0 && (unsigned)(stop_early >> 32) == ep - 1u;
+      if (tid == NT - 1 && stop_known) lds[L_GATE_IN] = __uint_as_float((unsigned)stop_early);
       if (own_p) {
         float v = taco_wave_sum(row_partial<TACO_NP>(lds + LP_W2 + wave * PW, lds + LP_H1, lane));
         v = v > 0.0f ? v : 0.0f;
         v = keep_now[256 + p_row] ? v * 2.0f : 0.0f;
-        taco_publish_lanes<TACO_REP_SMALL>(g + a.lay.p, a.lay.p_cap, p_row, ep, v, lane);
+        p_sent = taco_publish_lanes_kept<TACO_REP_SMALL>(g + a.lay.p, a.lay.p_cap, p_row, ep, v, lane);
       }
+      TACO_PSTAMP(2);
     }
     // ============ frame boundary: the previous frame's stop token ============
     if (t > 0) {
@@ -481,9 +505,9 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
       // One thread fetches the stop token.  (The P group does not poll for its layer-1 vector together
       // with it, although both are published at the same time: 32 x 256 early pollers on those lines delay
       // the stores they are waiting for by more than the second round trip costs.)
-      if (tid == NT - 1) lds[L_GATE_IN] = taco_wait_one(melv, NMEL, ep_prev, wctx, 0x100u);
+      if (tid == NT - 1 && !stop_known) lds[L_GATE_IN] = taco_wait_one(melv, NMEL, ep_prev, wctx, 0x100u);
       if (wctx.failed) lds[L_GATE_IN + 1] = 1.0f;
-      taco_lds_barrier();
+      taco_lds_barrier_only();
       if (lds[L_GATE_IN + 1] != 0.0f) break;
       if (!forced && taco_sigmoid(lds[L_GATE_IN]) > a.thr) { stopped = 1; break; }
     }
@@ -495,6 +519,7 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
 
     // ============ S3: attention LSTM ============
     taco_gather<NT>(g + a.lay.p + (j % TACO_REP_SMALL) * a.lay.p_cap, P, ep, lds + L_XP, wctx, 0x400u, nap_p);
+    taco_keep_alive(p_sent);
     TACO_STAMP(2);
     if (act_a) {
       dot_chunks<TACO_NP>(wa[0], wa[1], lds + L_XP, lane, acc_a);
@@ -634,7 +659,6 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
     TACO_STAMP(9);
 
     // ============ S8: mel / stop-token projection rows (M group), next frame's prenet layer 1 (P group) ============
-    if (is_p) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // next frame's keep bytes (LDS-DMA) have landed
     if (!is_p && !is_m) taco_gather_late<NT>(g + a.lay.dh + (j % TACO_REP_BIG) * a.lay.dh_cap, Rd, ep, lds + L_XDH, wctx, 0x900u, nap_dh);
     else taco_gather<NT>(g + a.lay.dh + (j % TACO_REP_BIG) * a.lay.dh_cap, Rd, ep, lds + L_XDH, wctx, 0x900u, nap_dh);
     TACO_STAMP(10);
@@ -839,12 +863,39 @@ int taco_decoder_collect(taco_handle h, int B, hipStream_t s) {
       fprintf(stderr, "  %-32s %7.2f\n  total %7.2f\n", "attn partial + frame top (mel / stop)", acc[TACO_STAMP_POINTS] / cnt, tot + acc[TACO_STAMP_POINTS] / cnt);
     }
     if (nfr > 8) {
+      // the same stamps on one time axis: mean offset of every point from workgroup 0's frame top of that frame
+      fprintf(stderr, "[taco stamps] offsets from workgroup 0's frame top (us): point, workgroups 0 / 32 / 200\n");
+      for (int k = 0; k < TACO_STAMP_POINTS; ++k) {
+        double off[3] = {0, 0, 0};
+        int cnt = 0;
+        for (int t = 4; t + 1 < nfr; ++t, ++cnt) {
+          const unsigned long long base = st[((size_t)0 * TACO_STAMP_FRAMES + t) * TACO_STAMP_POINTS];
+          for (int wg = 0; wg < 3; ++wg)
+            off[wg] += ((double)st[((size_t)wg * TACO_STAMP_FRAMES + t) * TACO_STAMP_POINTS + k] - (double)base) * 0.01;
+        }
+        fprintf(stderr, "  %-34s %7.2f %7.2f %7.2f\n", names[k], off[0] / cnt, off[1] / cnt, off[2] / cnt);
+      }
+    }
+    if (nfr > 8) {
       static const char* qn[6] = {"", "query rows", "energy terms", "barrier", "sum + publish", "barrier"};
       double acc[6] = {0};
       int cnt = 0;
       for (int t = 4; t + 1 < nfr; ++t, ++cnt) {
         const unsigned long long* r = &st[((size_t)3 * TACO_STAMP_FRAMES + t) * TACO_STAMP_POINTS];
         for (int k = 1; k < 6; ++k) acc[k] += (double)(r[k] - r[k - 1]) * 0.01;
+      }
+      {
+        double pa[3] = {0, 0, 0};
+        int pc = 0;
+        for (int t = 4; t + 1 < nfr; ++t, ++pc) {
+          const unsigned long long* r = &st[((size_t)3 * TACO_STAMP_FRAMES + t) * TACO_STAMP_POINTS + 6];
+          const unsigned long long top = st[((size_t)0 * TACO_STAMP_FRAMES + t) * TACO_STAMP_POINTS];
+          pa[0] += (double)(r[1] - r[0]) * 0.01;
+          pa[1] += (double)(r[2] - r[1]) * 0.01;
+          pa[2] += (double)(top - r[2]) * 0.01;
+        }
+        fprintf(stderr, "[taco stamps] workgroup 0 before its frame top: layer-1 gather %.2f, layer 2 + publish %.2f, stop test %.2f\n",
+                pa[0] / pc, pa[1] / pc, pa[2] / pc);
       }
       fprintf(stderr, "[taco stamps] inside the Q group's stage (workgroup 32):\n");
       for (int k = 1; k < 6; ++k) fprintf(stderr, "  %-32s %7.2f\n", qn[k], acc[k] / cnt);

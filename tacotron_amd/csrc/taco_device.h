@@ -119,6 +119,27 @@ __device__ __forceinline__ void taco_publish(taco_granule* base, int idx, unsign
   __hip_atomic_store((taco_ggran*)base + idx, word, TACO_RLX_AGENT);
 }
 
+// A store's address and data registers are read by the memory pipeline some time after the store has been
+// issued, and the compiler makes a wave wait for ALL its outstanding vector-memory operations (the
+// acknowledgement of the write-through store included, which takes longer than a poll) before it lets the
+// wave overwrite them.  A publish on the critical chain therefore keeps both alive - taco_keep_alive()
+// further down the frame - so that the register allocator cannot hand them out again right after the store.
+struct taco_sent {
+  taco_ggran* where;
+  taco_granule word;
+};
+__device__ __forceinline__ void taco_keep_alive(const taco_sent& s) { asm volatile("" ::"v"(s.where), "v"(s.word)); }
+// One value to the first R replicas' slot idx, spread over the first R lanes of a wave that all hold `value`.
+template <int R>
+__device__ __forceinline__ taco_sent taco_publish_lanes_kept(taco_granule* base, int cap, int idx, unsigned epoch, float value,
+                                                             int lane) {
+  taco_sent s;
+  s.where = (taco_ggran*)base + (size_t)lane * cap + idx;
+  s.word = ((taco_granule)epoch << 32) | (taco_granule)__float_as_uint(value);
+  if (lane < R) __hip_atomic_store(s.where, s.word, TACO_RLX_AGENT);
+  return s;
+}
+
 // Publishes one value to all R replicas of a vector (replica stride `cap` granules).
 template <int R>
 __device__ __forceinline__ void taco_publish_rep(taco_granule* base, int cap, int idx, unsigned epoch, float value) {
@@ -181,6 +202,13 @@ __device__ __forceinline__ void taco_lds_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// The same barrier spelled out, for places where the compiler's own version also waits for the wave's
+// outstanding vector-memory operations (it does where a poll loop joins just before the barrier): the wave's
+// publish store may still be on its way then, and its acknowledgement takes longer than a poll.
+__device__ __forceinline__ void taco_lds_barrier_only() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 // Naps.  A poll that reaches memory just before the value does costs a whole further round trip, and

@@ -68,7 +68,7 @@ traffic = {
   "hbm_bytes_per_frame": int(round((2.0 * fetch + write) * 1024.0 / FRAMES)),
   "command": f"rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python3 scripts/decode_once.py {FRAMES} 2",
   "note": "includes the one-time weight and folded-context load; per frame it is the 8-byte write-through "
-          "hand-off stores (16/8/4 replicas) and their polls. Algorithmic bytes per frame are 73.78 MB: "
+          "hand-off stores (with their replicas) and their polls. Algorithmic bytes per frame are 73.78 MB: "
           "the weights stay in registers.",
 }
 (dst / f"{tag}_pmc_traffic.json").write_text(json.dumps(traffic, indent=1) + "\n")

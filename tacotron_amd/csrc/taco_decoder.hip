@@ -543,8 +543,8 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
     if (act_d) dot_chunks<TACO_ND>(wd[0] + TACO_NA + NCTX, wd[1] + TACO_NA + NCTX, lds + L_XDH, lane, acc_d);
 
     // ============ S4: query rows and energy partial sums (Q group) ============
-    // only the Q group is in a hurry for the attention hidden state, only the P and M groups for the
-    // decoder hidden state: everyone else keeps its pollers away until the first granules have arrived
+    // only the Q group is in a hurry for the attention hidden state: everyone else keeps its pollers away until
+    // one wave has seen the first granules arrive (a nap instead measured slower here, unlike everywhere else)
     if (!is_q) taco_gather_late<NT>(g + a.lay.ah + (j % TACO_REP_BIG) * a.lay.ah_cap, Ra, ep, lds + L_XAH, wctx, 0x500u);
     else taco_gather<NT>(g + a.lay.ah + (j % TACO_REP_BIG) * a.lay.ah_cap, Ra, ep, lds + L_XAH, wctx, 0x500u);
     TACO_STAMP(4);
@@ -659,8 +659,7 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
     TACO_STAMP(9);
 
     // ============ S8: mel / stop-token projection rows (M group), next frame's prenet layer 1 (P group) ============
-    if (!is_p && !is_m) taco_gather_late<NT>(g + a.lay.dh + (j % TACO_REP_BIG) * a.lay.dh_cap, Rd, ep, lds + L_XDH, wctx, 0x900u, nap_dh);
-    else taco_gather<NT>(g + a.lay.dh + (j % TACO_REP_BIG) * a.lay.dh_cap, Rd, ep, lds + L_XDH, wctx, 0x900u, nap_dh);
+    taco_gather<NT>(g + a.lay.dh + (j % TACO_REP_BIG) * a.lay.dh_cap, Rd, ep, lds + L_XDH, wctx, 0x900u, nap_dh);
     TACO_STAMP(10);
     if (own_m) {
       acc_p += row_partial<TACO_ND>(my_proj, lds + L_XDH, lane);

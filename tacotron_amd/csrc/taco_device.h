@@ -280,18 +280,3 @@ __device__ __forceinline__ void taco_gather_late(const taco_granule* base, int n
     if (idx >= 64) lds_dst[idx] = taco_wait_one(base, idx, epoch, ctx, info);
   taco_lds_barrier();
 }
-// The same with the watching wave's nap.
-template <int NTHREADS>
-__device__ __forceinline__ void taco_gather_late(const taco_granule* base, int n, unsigned epoch, float* lds_dst,
-                                                 taco_wait_ctx& ctx, unsigned info, int& nap) {
-  if (threadIdx.x < 64) {
-    taco_nap(nap);
-    ctx.spun = 0;
-    if ((int)threadIdx.x < n) lds_dst[threadIdx.x] = taco_wait_one(base, threadIdx.x, epoch, ctx, info);
-    nap = taco_nap_adjust(nap, ctx.spun);
-  }
-  taco_lds_barrier();
-  for (int idx = threadIdx.x; idx < n; idx += NTHREADS)
-    if (idx >= 64) lds_dst[idx] = taco_wait_one(base, idx, epoch, ctx, info);
-  taco_lds_barrier();
-}

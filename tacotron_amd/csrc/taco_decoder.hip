@@ -498,18 +498,28 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
       TACO_PSTAMP(2);
     }
     // ============ frame boundary: the previous frame's stop token ============
-    if (t > 0) {
+    // 0 = go on, 1 = the previous frame was the last, 2 = a wait has given up
+    auto stop_test = [&]() -> int {
+      if (t == 0) return 0;
       const taco_granule* gp = a.gran + (size_t)((t - 1) & 1) * a.lay.per_parity;
-      const unsigned ep_prev = (unsigned)t;
       const taco_granule* melv = gp + a.lay.mel + (j % TACO_REP_SMALL) * a.lay.mel_cap;
       // One thread fetches the stop token.  (The P group does not poll for its layer-1 vector together
       // with it, although both are published at the same time: 32 x 256 early pollers on those lines delay
       // the stores they are waiting for by more than the second round trip costs.)
-      if (tid == NT - 1 && !stop_known) lds[L_GATE_IN] = taco_wait_one(melv, NMEL, ep_prev, wctx, 0x100u);
+      if (tid == NT - 1 && !stop_known) lds[L_GATE_IN] = taco_wait_one(melv, NMEL, (unsigned)t, wctx, 0x100u);
       if (wctx.failed) lds[L_GATE_IN + 1] = 1.0f;
       taco_lds_barrier_only();
-      if (lds[L_GATE_IN + 1] != 0.0f) break;
-      if (!forced && taco_sigmoid(lds[L_GATE_IN]) > a.thr) { stopped = 1; break; }
+      if (lds[L_GATE_IN + 1] != 0.0f) return 2;
+      return (!forced && taco_sigmoid(lds[L_GATE_IN]) > a.thr) ? 1 : 0;
+    };
+    // The P group, having published this frame's prenet output, goes on to its attention-LSTM rows before it
+    // looks at the stop token: its hidden-state values are the last the Q group waits for.  (What it computes
+    // for a frame that turns out not to exist is never read.)
+    const bool p_ahead = is_p && t < a.max_steps;
+    if (!p_ahead) {
+      const int st = stop_test();
+      if (st == 1) stopped = 1;
+      if (st != 0) break;
     }
     if (t == a.max_steps) break;
     TACO_STAMP(0);
@@ -538,6 +548,11 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
         for (int r = lane & 3; r < TACO_REP_BIG; r += 4) taco_publish(g + a.lay.ah + (size_t)r * a.lay.ah_cap, j * Ua + u, ep, hv);
     }
     TACO_STAMP(3);
+    if (p_ahead) {
+      const int st = stop_test();
+      if (st == 1) stopped = 1;
+      if (st != 0) break;
+    }
     // meanwhile: decoder-LSTM partial over the previous decoder hidden state
     float acc_d[2] = {0.0f, 0.0f};
     if (act_d) dot_chunks<TACO_ND>(wd[0] + TACO_NA + NCTX, wd[1] + TACO_NA + NCTX, lds + L_XDH, lane, acc_d);

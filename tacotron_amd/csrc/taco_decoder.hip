@@ -394,10 +394,9 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
   wctx.abort_word = (taco_gu32*)&a.ctl->abort_code;
   wctx.failed = 0;
   wctx.spun = 0;
-  // this wave's naps before it polls for the prenet output, the energy partials, the decoder hidden state and
-  // (P group) the layer-1 output.  Measured one by one: each of these shortens the frame, 1.5 us together; a nap
-  // before the attention hidden state (Q group) or the stop token does not.
-  int nap_p = 0, nap_pe = 0, nap_dh = 0, nap_h1 = 0;
+  // this wave's naps before it polls for each of the five vectors of a frame (the stop token's single poller
+  // needs none).  Measured: each nap shortens the frame, 2.2 us together.
+  int nap_p = 0, nap_pe = 0, nap_dh = 0, nap_h1 = 0, nap_ah = 0;
 
   const bool forced = a.forced_mel != nullptr;
   const int pad = (K - 1) / 2;
@@ -558,10 +557,7 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
     if (act_d) dot_chunks<TACO_ND>(wd[0] + TACO_NA + NCTX, wd[1] + TACO_NA + NCTX, lds + L_XDH, lane, acc_d);
 
     // ============ S4: query rows and energy partial sums (Q group) ============
-    // only the Q group is in a hurry for the attention hidden state: everyone else keeps its pollers away until
-    // one wave has seen the first granules arrive (a nap instead measured slower here, unlike everywhere else)
-    if (!is_q) taco_gather_late<NT>(g + a.lay.ah + (j % TACO_REP_BIG) * a.lay.ah_cap, Ra, ep, lds + L_XAH, wctx, 0x500u);
-    else taco_gather<NT>(g + a.lay.ah + (j % TACO_REP_BIG) * a.lay.ah_cap, Ra, ep, lds + L_XAH, wctx, 0x500u);
+    taco_gather<NT>(g + a.lay.ah + (j % TACO_REP_BIG) * a.lay.ah_cap, Ra, ep, lds + L_XAH, wctx, 0x500u, nap_ah);
     TACO_STAMP(4);
     if (is_q) {
       TACO_QSTAMP(0);

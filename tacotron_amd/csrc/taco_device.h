@@ -267,16 +267,3 @@ __device__ __forceinline__ void taco_gather(const taco_granule* base, int n, uns
   nap = taco_nap_adjust(nap, ctx.spun);
   taco_lds_barrier();
 }
-
-// Variant for consumers that are not in a hurry: one wave watches the first 64 granules, and only when
-// those have arrived do the other waves fetch the rest.  Early pollers on a vector's lines delay the
-// very stores they wait for, so consumers off the critical chain keep away until the data is there.
-template <int NTHREADS>
-__device__ __forceinline__ void taco_gather_late(const taco_granule* base, int n, unsigned epoch, float* lds_dst,
-                                                 taco_wait_ctx& ctx, unsigned info) {
-  if (threadIdx.x < 64 && (int)threadIdx.x < n) lds_dst[threadIdx.x] = taco_wait_one(base, threadIdx.x, epoch, ctx, info);
-  taco_lds_barrier();
-  for (int idx = threadIdx.x; idx < n; idx += NTHREADS)
-    if (idx >= 64) lds_dst[idx] = taco_wait_one(base, idx, epoch, ctx, info);
-  taco_lds_barrier();
-}

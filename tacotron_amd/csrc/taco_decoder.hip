@@ -37,6 +37,13 @@
 //     (computed once per model), so a Q workgroup needs no intermediate and reads E through scalar loads;
 //   * everything that does not depend on the value being waited for (the recurrent halves of the
 //     LSTM dot products, next frame's location term) is computed before the wait.
+//   * a consumer does not poll while it waits: it naps (s_sleep) for as long as the same hand-off took
+//     in the previous frames and then fetches the vector once; polls that reach memory before the value
+//     cost a further round trip each and delay the very stores they wait for (see taco_nap in
+//     taco_device.h).  Replicas of every vector spread what polling remains over more cache lines;
+//   * the P group runs ahead of the stop test (prenet layer 2 and its attention-LSTM rows of frame t+1
+//     are published before frame t's stop token is looked at; results of a frame that never runs are
+//     never read), because its values head the chain;
 // Granule slots are double-buffered by frame parity.  Every workgroup consumes the prenet output, the
 // attention hidden state, the energy partials and the stop token of frame t before it publishes its
 // decoder hidden state of frame t, and nothing of frame t+2 can be published before all decoder hidden

@@ -182,6 +182,13 @@ int taco_postnet(taco_handle h, const float* mel, const int32_t* n_frames, int32
  * the number of frames the longest utterance produced.  Synchronises on the stop event. */
 int taco_last_decode_timing(taco_handle h, double* total_us, int32_t* frames);
 
+/* Per-frame step latency (measurement helper, no counterpart in the reference): from now on the decoder
+ * kernel stores, for utterance 0 of every taco_decode call on this handle, the reading of the device's
+ * 100 MHz constant clock at the moment frame t's attention weights are final into ticks[t], t < capacity
+ * (device memory owned by the caller, which must stay valid until it is replaced or switched off with
+ * ticks = NULL).  Differences of consecutive entries x 10 ns are the latencies of the individual frames. */
+int taco_set_frame_clock(taco_handle h, uint64_t* ticks, int32_t capacity);
+
 #ifdef __cplusplus
 }
 #endif

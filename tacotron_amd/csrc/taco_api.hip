@@ -406,6 +406,14 @@ extern "C" int taco_postnet(taco_handle h, const float* mel, const int32_t* n_fr
   return TACO_OK;
 }
 
+extern "C" int taco_set_frame_clock(taco_handle h, uint64_t* ticks, int32_t capacity) {
+  if (!h) TACO_FAIL(TACO_EINVAL, "null handle");
+  if (ticks && capacity < 1) TACO_FAIL(TACO_EINVAL, "frame clock capacity %d", capacity);
+  h->frame_clock = reinterpret_cast<unsigned long long*>(ticks);
+  h->frame_clock_cap = ticks ? capacity : 0;
+  return TACO_OK;
+}
+
 extern "C" int taco_last_decode_timing(taco_handle h, double* total_us, int32_t* frames) {
   if (!h || !h->timing_valid) TACO_FAIL(TACO_EINVAL, "no decode has been timed on this handle");
   TACO_HIP(hipEventSynchronize(h->ev_stop));

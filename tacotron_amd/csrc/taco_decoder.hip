@@ -142,6 +142,8 @@ struct DecArgs {
   taco_granule* gran;
   taco_dec_layout lay;
   taco_dec_ctl* ctl;
+  unsigned long long* frame_clock;   // optional: clock reading per frame (measurement), or NULL
+  int frame_clock_cap;
 #ifdef TACO_STAMPS
   unsigned long long* stamps;   // diagnostic build only: [3 workgroups][TACO_STAMP_FRAMES][TACO_STAMP_POINTS]
 #endif
@@ -663,6 +665,7 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
       lds[L_CUM + HALO + tid] += w_own;
       if (j == n_wg - 1 && a.align) a.align[(size_t)t * a.T_in + tid] = w_own;
     }
+    if (a.frame_clock && j == n_wg - 1 && tid == 0 && t < a.frame_clock_cap) a.frame_clock[t] = wall_clock64();
     taco_lds_barrier();
     if (wave == 0) {
       const float hv = lstm_cell_lanes(lds + L_GATES, lds + L_BIAS + 16, lds + L_CELLS + 4, lane);
@@ -801,6 +804,8 @@ int taco_launch_decoder(taco_handle h, const float* memory, const float* pm, int
   a.shift_energies = h->energy_bound > 64.0f ? 1 : 0;
   a.forced_mel = forced_mel; a.mel = mel; a.gate = gate; a.align = align; a.n_frames_out = n_frames; a.reached_out = reached;
   a.gran = h->dec_gran; a.lay = h->dec_lay; a.ctl = h->dec_ctl + b;
+  a.frame_clock = b == 0 ? h->frame_clock : nullptr;
+  a.frame_clock_cap = h->frame_clock_cap;
 
   // folded context weights of this utterance: G = ctx_w_cat [rows][M] * memory^T [M][T_in], run as a
   // kernel-size-1 convolution over the position-major memory (columns >= len come out as zero)

@@ -111,6 +111,8 @@ struct taco_handle_s {
   int last_frames;
   int timing_valid;
   float energy_bound;        // sum |v_a|: no attention energy can exceed it in magnitude
+  unsigned long long* frame_clock;   // caller's device buffer for per-frame clock readings, or NULL
+  int frame_clock_cap;
 };
 
 // ---- launchers implemented in the kernel translation units ----------------------------------

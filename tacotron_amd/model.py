@@ -191,6 +191,24 @@ class Tacotron2:
     _lib.check(_lib.lib().taco_last_decode_timing(self._require(), C.byref(us), C.byref(frames)))
     return us.value, frames.value
 
+  def record_frame_clock(self, capacity: int) -> None:
+    """From now on utterance 0 of every decode leaves one reading of the device's 100 MHz clock per frame
+    (capacity frames at most; 0 switches it off).  See frame_latencies_us()."""
+    if capacity > 0:
+      self._frame_clock = torch.zeros(capacity, dtype=torch.int64, device=self.device)
+      ptr, cap = C.c_void_p(self._frame_clock.data_ptr()), capacity
+    else:
+      self._frame_clock, ptr, cap = None, C.c_void_p(0), 0
+    _lib.check(_lib.lib().taco_set_frame_clock(self._require(), ptr, cap))
+
+  def frame_latencies_us(self, n_frames: int) -> torch.Tensor:
+    """Latency of frames 1 .. n_frames-1 of the last decode's utterance 0 in microseconds (differences of
+    consecutive clock readings, 10 ns each), on the host."""
+    if getattr(self, "_frame_clock", None) is None:
+      raise RuntimeError("record_frame_clock() has not been called")
+    ticks = self._frame_clock[:min(n_frames, self._frame_clock.numel())].cpu()
+    return (ticks[1:] - ticks[:-1]).to(torch.float64) * 0.01
+
   # ---- whole path ------------------------------------------------------------------------------
   def inference_batch(self, symbols: torch.Tensor, stresses: Optional[torch.Tensor], tones: Optional[torch.Tensor],
                       durations: Optional[torch.Tensor], speakers: Optional[torch.Tensor],

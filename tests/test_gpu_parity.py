@@ -304,6 +304,17 @@ def test_full_size_properties(gate_table):
   assert bool(torch.isfinite(post).all())
   us, frames = gm.last_decode_timing()
   assert frames == 300 and us > 0
+  # per-frame clock: one increasing reading per frame, whose differences add up to about the launch's duration,
+  # and the frames it was recorded with are bit-identical to those without it
+  gm.record_frame_clock(300)
+  d = gm.decode(mem, pm, None, masks, 300, gate_threshold=never)
+  torch.cuda.synchronize()
+  lat = gm.frame_latencies_us(300)
+  us2, _ = gm.last_decode_timing()
+  gm.record_frame_clock(0)
+  assert lat.numel() == 299 and bool((lat > 0).all())
+  assert 0.5 * us2 < float(lat.sum()) < 1.05 * us2
+  assert torch.equal(d[0], c[0])
 
 
 def test_error_reporting():

@@ -161,6 +161,11 @@ constexpr int TACO_STAMP_FRAMES = 256, TACO_STAMP_POINTS = 12;
     if (tid == 0 && j == 32 && t < TACO_STAMP_FRAMES)                                                   \
       a.stamps[((size_t)3 * TACO_STAMP_FRAMES + t) * TACO_STAMP_POINTS + (k)] = wall_clock64();         \
   } while (0)
+#define TACO_QALL(k)                                                                                    \
+  do {                                                                                                  \
+    if (tid == 0 && is_q && t < TACO_STAMP_FRAMES)                                                      \
+      a.stamps[((size_t)(4 + (j - q_off)) * TACO_STAMP_FRAMES + t) * TACO_STAMP_POINTS + (k)] = wall_clock64(); \
+  } while (0)
 #define TACO_PSTAMP(k)                                                                                  \
   do {                                                                                                  \
     if (tid == 0 && j == 0 && t < TACO_STAMP_FRAMES)                                                    \
@@ -170,6 +175,7 @@ constexpr int TACO_STAMP_FRAMES = 256, TACO_STAMP_POINTS = 12;
 #define TACO_PSTAMP(k) do {} while (0)
 #define TACO_STAMP(k) do {} while (0)
 #define TACO_QSTAMP(k) do {} while (0)
+#define TACO_QALL(k) do {} while (0)
 #endif
 
 // Dot product of NC register-resident chunks with the activation vector in LDS.  Lane l holds
@@ -570,6 +576,7 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
     TACO_STAMP(4);
     if (is_q) {
       TACO_QSTAMP(0);
+      TACO_QALL(0);
       // wave w: query values of dimensions 2w, 2w+1, then their energy terms for every position (lane =
       // position); the 8 waves' partial sums meet in LDS
       float qv[2], vv[2];
@@ -600,6 +607,7 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
         }
       }
       TACO_QSTAMP(4);
+      TACO_QALL(1);
       taco_lds_barrier();                          // the per-wave partials' area is about to receive the gathered ones
       TACO_QSTAMP(5);
     }
@@ -824,7 +832,7 @@ int taco_launch_decoder(taco_handle h, const float* memory, const float* pm, int
   TACO_HIP(hipMemsetAsync(h->dec_gran, 0, gran_bytes, s));
 
 #ifdef TACO_STAMPS
-  const size_t stamp_count = (size_t)4 * TACO_STAMP_FRAMES * TACO_STAMP_POINTS;
+  const size_t stamp_count = (size_t)(4 + TACO_NQ_WG) * TACO_STAMP_FRAMES * TACO_STAMP_POINTS;
   if (!g_stamps_dev) TACO_HIP(hipMalloc((void**)&g_stamps_dev, stamp_count * 8));
   TACO_HIP(hipMemsetAsync(g_stamps_dev, 0, stamp_count * 8, s));
   a.stamps = g_stamps_dev;
@@ -862,7 +870,7 @@ int taco_decoder_collect(taco_handle h, int B, hipStream_t s) {
   }
 #ifdef TACO_STAMPS
   {
-    const size_t stamp_count = (size_t)4 * TACO_STAMP_FRAMES * TACO_STAMP_POINTS;
+    const size_t stamp_count = (size_t)(4 + TACO_NQ_WG) * TACO_STAMP_FRAMES * TACO_STAMP_POINTS;
     std::vector<unsigned long long> st(stamp_count);
     TACO_HIP(hipMemcpy(st.data(), g_stamps_dev, stamp_count * 8, hipMemcpyDeviceToHost));
     const int n_last = (int)h->dec_ctl_host[B - 1].n_frames;
@@ -919,6 +927,19 @@ int taco_decoder_collect(taco_handle h, int B, hipStream_t s) {
         fprintf(stderr, "[taco stamps] workgroup 0 before its frame top: layer-1 gather %.2f, layer 2 + publish %.2f, stop test %.2f\n",
                 pa[0] / pc, pa[1] / pc, pa[2] / pc);
       }
+      fprintf(stderr, "[taco stamps] every Q workgroup, offsets from workgroup 0's frame top: hidden state arrived / partials published\n ");
+      for (int q = 0; q < TACO_NQ_WG; ++q) {
+        double o0 = 0, o1 = 0;
+        int c2 = 0;
+        for (int t = 4; t + 1 < nfr; ++t, ++c2) {
+          const unsigned long long base = st[((size_t)0 * TACO_STAMP_FRAMES + t) * TACO_STAMP_POINTS];
+          const unsigned long long* r = &st[((size_t)(4 + q) * TACO_STAMP_FRAMES + t) * TACO_STAMP_POINTS];
+          o0 += ((double)r[0] - (double)base) * 0.01;
+          o1 += ((double)r[1] - (double)base) * 0.01;
+        }
+        fprintf(stderr, " %.2f/%.2f", o0 / c2, o1 / c2);
+      }
+      fprintf(stderr, "\n");
       fprintf(stderr, "[taco stamps] inside the Q group's stage (workgroup 32):\n");
       for (int k = 1; k < 6; ++k) fprintf(stderr, "  %-32s %7.2f\n", qn[k], acc[k] / cnt);
     }

@@ -114,9 +114,15 @@ __device__ __forceinline__ float taco_quad_bcast(float v) { return __shfl(v, (th
 #endif
 
 // ---- hand-off: one 8-byte word carries {epoch, fp32}; the data is its own flag -------------------
+// A word leaves as an atomic exchange whose result nobody looks at (global_atomic_swap_x2 without return),
+// not as a store: the exchange is carried out at the memory side right away, and the frame came out
+// 0.07 us shorter than with write-through stores.
+__device__ __forceinline__ void taco_send(taco_ggran* where, taco_granule word) {
+  (void)__hip_atomic_exchange(where, word, TACO_RLX_AGENT);
+}
 __device__ __forceinline__ void taco_publish(taco_granule* base, int idx, unsigned epoch, float value) {
   const taco_granule word = ((taco_granule)epoch << 32) | (taco_granule)__float_as_uint(value);
-  __hip_atomic_store((taco_ggran*)base + idx, word, TACO_RLX_AGENT);
+  taco_send((taco_ggran*)base + idx, word);
 }
 
 // A store's address and data registers are read by the memory pipeline some time after the store has been
@@ -136,7 +142,7 @@ __device__ __forceinline__ taco_sent taco_publish_lanes_kept(taco_granule* base,
   taco_sent s;
   s.where = (taco_ggran*)base + (size_t)lane * cap + idx;
   s.word = ((taco_granule)epoch << 32) | (taco_granule)__float_as_uint(value);
-  if (lane < R) __hip_atomic_store(s.where, s.word, TACO_RLX_AGENT);
+  if (lane < R) taco_send(s.where, s.word);
   return s;
 }
 
@@ -145,7 +151,7 @@ template <int R>
 __device__ __forceinline__ void taco_publish_rep(taco_granule* base, int cap, int idx, unsigned epoch, float value) {
   const taco_granule word = ((taco_granule)epoch << 32) | (taco_granule)__float_as_uint(value);
 #pragma unroll
-  for (int r = 0; r < R; ++r) __hip_atomic_store((taco_ggran*)base + (size_t)r * cap + idx, word, TACO_RLX_AGENT);
+  for (int r = 0; r < R; ++r) taco_send((taco_ggran*)base + (size_t)r * cap + idx, word);
 }
 
 // The same, spread over the first R lanes of a wave that all hold `value`: one store instruction.
@@ -153,7 +159,7 @@ template <int R>
 __device__ __forceinline__ void taco_publish_lanes(taco_granule* base, int cap, int idx, unsigned epoch, float value,
                                                    int lane) {
   const taco_granule word = ((taco_granule)epoch << 32) | (taco_granule)__float_as_uint(value);
-  if (lane < R) __hip_atomic_store((taco_ggran*)base + (size_t)lane * cap + idx, word, TACO_RLX_AGENT);
+  if (lane < R) taco_send((taco_ggran*)base + (size_t)lane * cap + idx, word);
 }
 
 #ifndef TACO_POLL_SLEEP

@@ -685,6 +685,7 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
     // meanwhile: folded-context half of my projection rows (M group)
     float acc_p = 0.0f;
     if (own_m) acc_p = row_partial<NCTX>(my_proj + TACO_ND * TACO_CHUNK, aw, lane);
+    if (own_p && !forced) acc_p = row_partial<NCTX>(my_wf + TACO_ND * TACO_CHUNK, aw, lane) + (lane == 0 ? lds[LP_BIAS + wave] : 0.0f);   // ... of my folded layer-1 row, with its bias
     TACO_STAMP(9);
 
     // ============ S8: mel / stop-token projection rows (M group), next frame's prenet layer 1 (P group) ============
@@ -713,8 +714,7 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
         }
         x1 = taco_wave_sum(acc);
       } else {
-        x1 = taco_wave_sum(row_partial<TACO_ND>(my_wf, lds + L_XDH, lane) + row_partial<NCTX>(my_wf + TACO_ND * TACO_CHUNK, aw, lane)) +
-             lds[LP_BIAS + wave];
+        x1 = taco_wave_sum(row_partial<TACO_ND>(my_wf, lds + L_XDH, lane) + acc_p);
       }
       x1 = x1 > 0.0f ? x1 : 0.0f;
       x1 = keep_lds[((t + 1) & 1) * 512 + p_row] ? x1 * 2.0f : 0.0f;

@@ -443,6 +443,14 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
     const int col = lane & 15, kq = lane >> 4;
     _Pragma("unroll 1") for (int s0 = wave * 16; s0 < len; s0 += NW * 16) {
       const int s = s0 + col;
+      // processed memory of this tile: LDS copy if the utterance fits, else from global memory (L2), asked for
+      // before the products so that the round trip runs beside them
+      float pmv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (len > LQ_PM_POS) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (s < len && 4 * kq + r < q_cnt) pmv[r] = a.pm[(size_t)s * A + q_base + 4 * kq + r];
+      }
       taco_f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll LOC_UNROLL
       for (int m = 0; m < LOC_KSTEPS; ++m) {
@@ -455,10 +463,8 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int d = 4 * kq + r;
-        float pmv;                                 // processed memory: LDS copy if the utterance fits, else global
-        if (len <= LQ_PM_POS) pmv = lds[LQ_PM + d * LQ_PM_POS + s0 + col];
-        else pmv = (s < len && d < q_cnt) ? a.pm[(size_t)s * A + q_base + d] : 0.0f;
-        lds[LQ_U + d * TACO_MAX_TIN + s] = acc[r] + pmv;
+        if (len <= LQ_PM_POS) pmv[r] = lds[LQ_PM + d * LQ_PM_POS + s0 + col];
+        lds[LQ_U + d * TACO_MAX_TIN + s] = acc[r] + pmv[r];
       }
     }
   };

@@ -257,13 +257,14 @@ def test_no_step_limit_stops_on_the_stop_token():
 
 
 def test_long_input_full_size_model(gate_table):
-  """Default-geometry model with more than 256 input positions (two folded-context chunks, several
-  position tiles per wave in the location term), against the oracle."""
+  """Default-geometry model over the range of input lengths - a single symbol, lengths around the 256-position
+  boundary of the folded-context chunks, the 512-position capacity (several position tiles per wave in the
+  location term) - against the oracle."""
   gate = gate_table["ljs"]
   om = oracle_model("ljs", gate)
   gm = gpu_model("ljs", gate)
   ck = scenario_checkpoint("ljs", gate)
-  for T_in, max_steps in ((384, 8), (512, 5)):
+  for T_in, max_steps in ((1, 6), (64, 40), (129, 12), (256, 8), (257, 8), (384, 8), (512, 5)):
     ids = scenarios.random_ids(ck, [T_in], seed=900 + T_in)
     masks = prenet_keep_masks(3, max_steps, om.dims.P)
     mem_o, pm_o = om.encode(chans(ids), ids["speakers"], None)

@@ -281,6 +281,33 @@ def test_long_input_full_size_model(gate_table):
     gm.decode(mem, pm, None, prenet_keep_masks(3, 2, om.dims.P), 2)
 
 
+def test_padded_batch_across_the_chunk_boundary(gate_table):
+  """A padded batch whose longest line has more than 256 symbols (so every utterance runs the instance with two
+  folded-context chunks) while others are short or exactly 256: each utterance must equal its own unpadded
+  oracle run, and everything past its length and its frames must be zero."""
+  for name, lens, max_steps in (("tiny", [300, 40, 256, 7], 10), ("ljs", [260, 33], 6)):
+    gate = gate_table[name]
+    om = oracle_model(name, gate)
+    gm = gpu_model(name, gate)
+    ck = scenario_checkpoint(name, gate)
+    ids = scenarios.random_ids(ck, lens, seed=4242)
+    for b in range(len(lens)):                    # one speaker per utterance is all the oracle call below needs
+      ids["speakers"][b, :] = ids["speakers"][b, 0]
+    masks = prenet_keep_masks(11, max_steps, om.dims.P)
+    lens_d = dev(np.array(lens, np.int32))
+    mem, pm = gm.encode([dev(c) for c in chans(ids)], dev(ids["speakers"]), lens_d)
+    mel, gate_g, align, nf, reached = gm.decode(mem, pm, lens_d, masks, max_steps, gate_threshold=2.0)
+    assert nf.cpu().tolist() == [max_steps] * len(lens)
+    for b, ln in enumerate(lens):
+      one = {k: (None if v is None else v[b:b + 1, :ln]) for k, v in ids.items() if k != "lens"}
+      mem_o, pm_o = om.encode(chans(one), one["speakers"], None)
+      mel_o, gate_o, align_o, _, _, _ = om.decode(mem_o, pm_o, None, masks.numpy(), max_steps, gate_threshold=2.0)
+      np.testing.assert_allclose(mem[b, :ln].cpu().numpy(), mem_o[0], atol=TF_TOL, rtol=0)
+      np.testing.assert_allclose(mel[b].cpu().numpy(), mel_o[0], atol=FREE_TOL, rtol=0)
+      np.testing.assert_allclose(align[b, :, :ln].cpu().numpy(), align_o[0], atol=FREE_TOL, rtol=0)
+      assert not align[b, :, ln:].any() and not mem[b, ln:].any()
+
+
 def test_full_size_properties(gate_table):
   """Size-independent checks at the benchmark's extents (1000 frames of the LJS-sized model):
   bit-reproducibility, the prefix property (fewer allowed steps = a prefix of the longer run),

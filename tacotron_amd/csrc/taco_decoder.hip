@@ -553,8 +553,8 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
     TACO_STAMP(2);
     if (act_a) {
       dot_chunks<TACO_NP>(wa[0], wa[1], lds + L_XP, lane, acc_a);
-      const float s0 = taco_wave_sum(acc_a[0]);
-      const float s1 = taco_wave_sum(acc_a[1]);
+      float s0, s1;
+      taco_wave_sum2(acc_a[0], acc_a[1], s0, s1);
       if (lane == 0) {
         lds[L_GATES + wave * 2 + 0] = s0;
         lds[L_GATES + wave * 2 + 1] = s1;
@@ -588,8 +588,7 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
       float qv[2], vv[2];
       row_partial2<TACO_NA>(lds + LQ_ROWS + (wave * 2) * (TACO_NA * TACO_CHUNK), lds + LQ_ROWS + (wave * 2 + 1) * (TACO_NA * TACO_CHUNK),
                             lds + L_XAH, lane, qv[0], qv[1]);
-      qv[0] = taco_wave_sum(qv[0]);
-      qv[1] = taco_wave_sum(qv[1]);
+      taco_wave_sum2(qv[0], qv[1], qv[0], qv[1]);
       vv[0] = lds[LQ_V + wave * 2];           // rows beyond my dimensions: zero row, v = 0, finite U
       vv[1] = lds[LQ_V + wave * 2 + 1];
       TACO_QSTAMP(1);
@@ -665,8 +664,8 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
     if (act_d) {
 #pragma unroll
       for (int c = 0; c < NCTX; ++c) dot_reg(wd[0][TACO_NA + c], wd[1][TACO_NA + c], wgt[c], acc_d);
-      const float s0 = taco_wave_sum(acc_d[0]);
-      const float s1 = taco_wave_sum(acc_d[1]);
+      float s0, s1;
+      taco_wave_sum2(acc_d[0], acc_d[1], s0, s1);
       if (lane == 0) {
         lds[L_GATES + wave * 2 + 0] = s0;
         lds[L_GATES + wave * 2 + 1] = s1;

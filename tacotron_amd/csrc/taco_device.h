@@ -51,6 +51,19 @@ __device__ __forceinline__ float taco_wave_sum(float v) {
   v += taco_dpp_rot<0x121>(v);
   return (taco_lane_value(v, 0) + taco_lane_value(v, 16)) + (taco_lane_value(v, 32) + taco_lane_value(v, 48));
 }
+// Two wave-wide sums for the price of one: v_permlane32_swap puts the upper half of `a` beside the lower half of
+// `b`, so that one addition leaves a's lanes folded onto lanes 0..31 and b's onto lanes 32..63; the rotations inside
+// the rows of 16 and two v_readlane per value finish both.
+__device__ __forceinline__ void taco_wave_sum2(float a, float b, float& sum_a, float& sum_b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  float v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  v += taco_dpp_rot<0x128>(v);
+  v += taco_dpp_rot<0x124>(v);
+  v += taco_dpp_rot<0x122>(v);
+  v += taco_dpp_rot<0x121>(v);
+  sum_a = taco_lane_value(v, 0) + taco_lane_value(v, 16);
+  sum_b = taco_lane_value(v, 32) + taco_lane_value(v, 48);
+}
 // Sum over each aligned group of 8 lanes (quad swaps, then the half-row mirror); every lane of a
 // group receives the group's total.
 __device__ __forceinline__ float taco_sum8(float v) {
@@ -93,6 +106,10 @@ __device__ __forceinline__ float taco_wave_max(float v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
   return v;
+}
+__device__ __forceinline__ void taco_wave_sum2(float a, float b, float& sum_a, float& sum_b) {
+  sum_a = taco_wave_sum(a);
+  sum_b = taco_wave_sum(b);
 }
 __device__ __forceinline__ float taco_sum8(float v) {
   v += __shfl_xor(v, 4, 64);

@@ -671,14 +671,6 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
         lds[L_GATES + wave * 2 + 1] = s1;
       }
     }
-    // each thread leaves its position's weight in LDS for the projection rows, the location term and the
-    // next frame's attention-LSTM partial sums, accumulates it, and the last workgroup writes the alignment row
-    lds[L_AW + HALO + tid] = w_own;
-    if (tid < len) {
-      lds[L_CUM + HALO + tid] += w_own;
-      if (j == n_wg - 1 && a.align) a.align[(size_t)t * a.T_in + tid] = w_own;
-    }
-    if (a.frame_clock && j == n_wg - 1 && tid == 0 && t < a.frame_clock_cap) a.frame_clock[t] = wall_clock64();
     taco_lds_barrier();
     if (wave == 0) {
       const float hv = lstm_cell_lanes(lds + L_GATES, lds + L_BIAS + 16, lds + L_CELLS + 4, lane);
@@ -686,6 +678,16 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
       if (u < Ud && j * Ud + u < Rd)
         for (int r = lane & 3; r < TACO_REP_BIG; r += 4) taco_publish(g + a.lay.dh + (size_t)r * a.lay.dh_cap, j * Ud + u, ep, hv);
     }
+    // Behind the publish: each thread leaves its position's weight in LDS for the projection rows, the location
+    // term and the next frame's attention-LSTM partial sums, accumulates it, and the last workgroup writes the
+    // alignment row.
+    lds[L_AW + HALO + tid] = w_own;
+    if (tid < len) {
+      lds[L_CUM + HALO + tid] += w_own;
+      if (j == n_wg - 1 && a.align) a.align[(size_t)t * a.T_in + tid] = w_own;
+    }
+    if (a.frame_clock && j == n_wg - 1 && tid == 0 && t < a.frame_clock_cap) a.frame_clock[t] = wall_clock64();
+    taco_lds_barrier();
     TACO_STAMP(8);
     // meanwhile: folded-context half of my projection rows (M group)
     float acc_p = 0.0f;

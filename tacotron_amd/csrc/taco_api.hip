@@ -64,6 +64,19 @@ int ensure_floats(float** p, size_t* have, size_t want) {
   return TACO_OK;
 }
 
+// Makes the handle's device current for the duration of an entry point and gives the caller its own back.
+struct DeviceScope {
+  int prev = -1;
+  hipError_t status;
+  explicit DeviceScope(int device) {
+    (void)hipGetDevice(&prev);
+    status = hipSetDevice(device);
+  }
+  ~DeviceScope() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
 }  // namespace
 
 extern "C" int taco_create(const taco_dims* dims, const taco_weights* weights, int device, taco_handle* out) {
@@ -77,7 +90,8 @@ extern "C" int taco_create(const taco_dims* dims, const taco_weights* weights, i
   if (esum != d.E) TACO_FAIL(TACO_EINVAL, "channel widths sum to %d but E = %d", esum, d.E);
   if (d.H_e != (d.E + 1) / 2 || d.M != 2 * d.H_e + d.S) TACO_FAIL(TACO_EINVAL, "inconsistent extents: E=%d H_e=%d S=%d M=%d", d.E, d.H_e, d.S, d.M);
 
-  TACO_HIP(hipSetDevice(device));
+  DeviceScope on_device(device);
+  TACO_HIP(on_device.status);
   {
     const int prc = taco_conv_prepare();
     if (prc != TACO_OK) return prc;
@@ -252,7 +266,7 @@ extern "C" int taco_create(const taco_dims* dims, const taco_weights* weights, i
 
 extern "C" int taco_destroy(taco_handle h) {
   if (!h) return TACO_OK;
-  (void)hipSetDevice(h->device);
+  DeviceScope on_device(h->device);
   (void)hipDeviceSynchronize();
   if (h->pool) (void)hipFree(h->pool);
   for (int i = 0; i < 2; ++i)
@@ -295,7 +309,8 @@ extern "C" int taco_encode(taco_handle h, const int64_t* const* ids, const int64
   if (B < 1 || T_in < 1) TACO_FAIL(TACO_EINVAL, "taco_encode: B = %d, T_in = %d", B, T_in);
   hipStream_t s = (hipStream_t)stream;
   const taco_dims& d = h->d;
-  TACO_HIP(hipSetDevice(h->device));
+  DeviceScope on_device(h->device);
+  TACO_HIP(on_device.status);
   int rc = ensure_act(h, (size_t)B * d.E * T_in);
   if (rc != TACO_OK) return rc;
   rc = ensure_floats(&h->ws_gx, &h->ws_gx_floats, (size_t)B * 8 * d.H_e * T_in);
@@ -334,7 +349,8 @@ int taco_check_encoder_flags(taco_handle h, hipStream_t s) {
 extern "C" int taco_encode_status(taco_handle h, void* stream) {
   if (!h) TACO_FAIL(TACO_EINVAL, "taco_encode_status: NULL handle");
   hipStream_t s = (hipStream_t)stream;
-  TACO_HIP(hipSetDevice(h->device));
+  DeviceScope on_device(h->device);
+  TACO_HIP(on_device.status);
   TACO_HIP(hipMemcpyAsync(h->enc_ctl_host, h->enc_ctl, 64, hipMemcpyDeviceToHost, s));
   TACO_HIP(hipStreamSynchronize(s));
   return taco_check_encoder_flags(h, s);
@@ -349,7 +365,8 @@ extern "C" int taco_decode(taco_handle h, const float* memory, const float* proc
   if (B < 1) TACO_FAIL(TACO_EINVAL, "taco_decode: B = %d", B);
   hipStream_t s = (hipStream_t)stream;
   const taco_dims& d = h->d;
-  TACO_HIP(hipSetDevice(h->device));
+  DeviceScope on_device(h->device);
+  TACO_HIP(on_device.status);
   if (B > h->dec_ctl_cap) {
     taco_dec_ctl *dev = nullptr, *host = nullptr;
     const int cap = B + 64;
@@ -387,7 +404,8 @@ extern "C" int taco_postnet(taco_handle h, const float* mel, const int32_t* n_fr
   if (B < 1 || T_cap < 1) TACO_FAIL(TACO_EINVAL, "taco_postnet: B = %d, T_cap = %d", B, T_cap);
   hipStream_t s = (hipStream_t)stream;
   const taco_dims& d = h->d;
-  TACO_HIP(hipSetDevice(h->device));
+  DeviceScope on_device(h->device);
+  TACO_HIP(on_device.status);
   const int cmax = d.C_post > d.n_mel ? d.C_post : d.n_mel;
   int rc = ensure_act(h, (size_t)B * cmax * T_cap);
   if (rc != TACO_OK) return rc;

@@ -73,6 +73,35 @@ traffic = {
 }
 (dst / f"{tag}_pmc_traffic.json").write_text(json.dumps(traffic, indent=1) + "\n")
 
+# optional: SQ counter passes of the decoder (averages per 1000-frame dispatch)
+sq = {}
+for sub in ("sqa", "sqb"):
+  if not sorted((src / sub).rglob("*_results.db")):
+    continue
+  con = db(src / sub)
+  q = ("select counter_name, avg(v) from (select counter_name, dispatch_id, sum(value) as v from counters_collection "
+       "where kernel_name like '%taco_decoder_kernel%' group by counter_name, dispatch_id) group by counter_name")
+  for cname, avg in con.execute(q):
+    sq[cname] = avg
+if sq:
+  derived = {}
+  if sq.get("SQ_WAVE_CYCLES"):
+    wc = sq["SQ_WAVE_CYCLES"]
+    for k in ("SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_SCA",
+              "SQ_WAIT_INST_ANY"):
+      if k in sq:
+        derived[k + "_per_WAVE_CYCLE"] = round(sq[k] / wc, 4)
+  if sq.get("SQ_LDS_IDX_ACTIVE"):
+    derived["lds_bank_conflict_cycles_per_active_cycle"] = round(sq.get("SQ_LDS_BANK_CONFLICT", 0.0) / sq["SQ_LDS_IDX_ACTIVE"], 4)
+  for k in ("SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_VALU_TRANS_F32"):
+    if k in sq:
+      derived[k + "_per_frame"] = round(sq[k] / FRAMES, 1)
+  (dst / f"{tag}_pmc_sq.json").write_text(json.dumps({
+    "kernel": "taco_decoder_kernel", "frames_per_launch": FRAMES, "per_dispatch": {k: round(v, 1) for k, v in sorted(sq.items())},
+    "derived": derived,
+    "command": f"rocprofv3 --pmc <8 SQ counters per pass> -- python3 scripts/decode_once.py {FRAMES} 2 (scripts/profile_round.sh)",
+  }, indent=1) + "\n")
+
 for a, b in (("bench.json", f"{tag}_bench.json"), ("bench_under_prof.json", f"{tag}_bench_under_rocprof.json")):
   if (src / a).exists():
     shutil.copy(src / a, dst / b)

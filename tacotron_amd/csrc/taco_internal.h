@@ -45,9 +45,9 @@ typedef unsigned long long taco_granule;
 // is stored in several identical replicas (producers write all, consumer workgroup j polls replica
 // j % R): 256 pollers on the few cache lines of a short vector is what limits a hand-off's latency.
 #ifndef TACO_RS
-#define TACO_RS 8
+#define TACO_RS 4
 #define TACO_RP 2
-#define TACO_RB 4
+#define TACO_RB 2
 #endif
 constexpr int TACO_REP_SMALL = TACO_RS;   // prenet layer outputs, stop token (<= 256 granules)
 constexpr int TACO_REP_PE = TACO_RP;      // energy partial sums (8 groups x positions)

@@ -8,6 +8,8 @@ from tacotron_amd import cli, scenarios
 
 n_lines = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 400
+if "TACO_WRITE_BEHIND" in os.environ:            # 0 = wait for every line's files before the next line (for comparison)
+  cli.WRITE_BEHIND = int(os.environ["TACO_WRITE_BEHIND"])
 ckpt = scenarios.checkpoint("ljs")
 r = np.random.RandomState(7)
 with tempfile.TemporaryDirectory() as tmp:

@@ -20,6 +20,8 @@ from __future__ import annotations
 
 import argparse
 import codecs
+import collections
+import concurrent.futures
 import datetime
 import logging
 import os
@@ -37,6 +39,7 @@ from tacotron_amd.config import parse_hparams_string
 
 DEFAULT_MAX_DECODER_STEPS = 3000     # reference: src/tacotron_cli/defaults.py
 DEFAULT_DEVICE = "cuda:0"
+WRITE_BEHIND = 16                     # lines whose files may still be on their way to the disk
 
 Utterances = "OrderedDict[int, List[str]]"
 Paragraphs = "OrderedDict[int, OrderedDict[int, List[str]]]"
@@ -170,16 +173,28 @@ def synthesize_plan(synth, plan: Sequence[PlannedLine], speaker: Optional[str], 
   costs = [sharding.predicted_cost(len(item.symbols)) for item in plan]
 
   def work(indices: List[int]) -> Dict[int, Dict[str, object]]:
+    # The files of one line are written by a single background thread while the GPU works on the next
+    # line; at most WRITE_BEHIND lines wait for the disk, and a failed write surfaces at its own line.
+    pending: "collections.deque" = collections.deque()
     out: Dict[int, Dict[str, object]] = {}
-    for group_idx in sharding.batches(indices, batch_size):
-      if batch_size == 1:
-        results = [synth.infer(symbols=plan[group_idx[0]].symbols, speaker=speaker, include_stats=include_stats,
-                               max_decoder_steps=max_decoder_steps, seed=seed)]
-      else:
-        results = synth.infer_batch([plan[i].symbols for i in group_idx], speaker=speaker,
-                                    max_decoder_steps=max_decoder_steps, seed=seed, include_stats=include_stats)
-      for i, res in zip(group_idx, results):
-        out[i] = _write_line(plan[i], res, include_stats)
+
+    def settle(limit: int) -> None:
+      while len(pending) > limit:
+        i, future = pending.popleft()
+        out[i] = future.result()
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="taco-write") as writer:
+      for group_idx in sharding.batches(indices, batch_size):
+        if batch_size == 1:
+          results = [synth.infer(symbols=plan[group_idx[0]].symbols, speaker=speaker, include_stats=include_stats,
+                                 max_decoder_steps=max_decoder_steps, seed=seed)]
+        else:
+          results = synth.infer_batch([plan[i].symbols for i in group_idx], speaker=speaker,
+                                      max_decoder_steps=max_decoder_steps, seed=seed, include_stats=include_stats)
+        for i, res in zip(group_idx, results):
+          pending.append((i, writer.submit(_write_line, plan[i], res, include_stats)))
+        settle(WRITE_BEHIND)
+      settle(0)
     return out
 
   return sharding.run_sharded(len(plan), costs, work, group=group)

@@ -308,6 +308,44 @@ def test_padded_batch_across_the_chunk_boundary(gate_table):
       assert not align[b, :, ln:].any() and not mem[b, ln:].any()
 
 
+def test_batch_of_64_equals_single_runs_at_full_size(gate_table):
+  """The batched configuration at the LJS-sized model's extents: 64 ragged lines (40..160 symbols) in one padded
+  batch, stop test live.  Size-independent property: every utterance of the batch equals the same line run alone
+  (encoder outputs, frames, gate values, alignments, frame count), and everything past an utterance's length and
+  frames is zero.  Tolerance 1e-5: the arithmetic per utterance is the same, only buffer strides differ."""
+  gate = gate_table["ljs"]
+  gm = gpu_model("ljs", gate)
+  ck = scenario_checkpoint("ljs", gate)
+  r = np.random.RandomState(64)
+  lens = [int(v) for v in r.randint(40, 161, size=64)]
+  lens[0], lens[1] = 160, 40
+  max_steps = 120
+  ids = scenarios.random_ids(ck, lens, seed=6464)
+  masks = prenet_keep_masks(5, max_steps, gm.dims.P)
+  lens_d = dev(np.array(lens, np.int32))
+  mem, pm = gm.encode([dev(c) for c in chans(ids)], dev(ids["speakers"]), lens_d)
+  mel, gate_g, align, nf, reached = gm.decode(mem, pm, lens_d, masks, max_steps)
+  post = gm.postnet(mel, nf)
+  nf_l = nf.cpu().tolist()
+  assert all(1 <= n <= max_steps for n in nf_l)
+  for b in (0, 1, 2, 17, 40, 63):
+    ln = lens[b]
+    one = {k: (None if v is None else v[b:b + 1, :ln]) for k, v in ids.items() if k != "lens"}
+    mem1, pm1 = gm.encode([dev(c) for c in chans(one)], dev(one["speakers"]), None)
+    mel1, gate1, align1, nf1, reached1 = gm.decode(mem1, pm1, None, masks, max_steps)
+    post1 = gm.postnet(mel1, nf1)
+    n = int(nf1[0])
+    assert nf_l[b] == n and bool(reached[b]) == bool(reached1[0])
+    tol = dict(atol=1e-5, rtol=0)
+    np.testing.assert_allclose(mem[b, :ln].cpu().numpy(), mem1[0].cpu().numpy(), **tol)
+    np.testing.assert_allclose(mel[b, :, :n].cpu().numpy(), mel1[0, :, :n].cpu().numpy(), **tol)
+    np.testing.assert_allclose(post[b, :, :n].cpu().numpy(), post1[0, :, :n].cpu().numpy(), **tol)
+    np.testing.assert_allclose(gate_g[b, :n].cpu().numpy(), gate1[0, :n].cpu().numpy(), **tol)
+    np.testing.assert_allclose(align[b, :n, :ln].cpu().numpy(), align1[0, :n, :ln].cpu().numpy(), **tol)
+    assert not mem[b, ln:].any() and not align[b, :, ln:].any()
+    assert not mel[b, :, n:].any() and not post[b, :, n:].any()
+
+
 def test_full_size_properties(gate_table):
   """Size-independent checks at the benchmark's extents (1000 frames of the LJS-sized model):
   bit-reproducibility, the prefix property (fewer allowed steps = a prefix of the longer run),

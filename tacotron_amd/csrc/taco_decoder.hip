@@ -12,8 +12,9 @@
 //     4j..4j+3 of each LSTM, wave w holds two gate rows (2*(w&1), +1) of unit (w>>1), laid out so a
 //     lane's 4 weights of a chunk meet one ds_read_b128 of the activation vector;
 //   * workgroups exchange activation vectors through 8-byte {epoch, fp32} granules written with
-//     agent-scope (write-through) stores and polled with agent-scope loads: the value is its own
-//     ready flag, so no grid barrier and no cache fence sits between the dependent steps;
+//     agent-scope atomic exchanges whose result is dropped (carried out at the memory side, see
+//     taco_send) and polled with agent-scope loads: the value is its own ready flag, so no grid
+//     barrier and no cache fence sits between the dependent steps;
 //   * the attention context never travels: ctx = sum_s w_s * memory_s enters the frame only through
 //     W * ctx (both LSTMs' input rows and the projection rows), and W * ctx = (W * memory^T) * w.
 //     G = W_ctx * memory^T is computed once per utterance (a GEMM before this launch); the kernel keeps

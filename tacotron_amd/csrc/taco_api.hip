@@ -246,7 +246,7 @@ extern "C" int taco_create(const taco_dims* dims, const taco_weights* weights, i
   // ---- hand-off words, control blocks, events ----
   taco_decoder_fill_layout(&h->dec_lay, h->n_cu);
   TACO_CREATE_HIP(hipMalloc((void**)&h->dec_gran, taco_decoder_granules(h->n_cu) * sizeof(taco_granule)));
-  h->enc_gran_count = taco_enc_lstm_granules();
+  h->enc_gran_count = taco_enc_lstm_granules(h->n_cu);
   TACO_CREATE_HIP(hipMalloc((void**)&h->enc_gran, h->enc_gran_count * sizeof(taco_granule)));
   h->dec_ctl_cap = 64;
   TACO_CREATE_HIP(hipMalloc((void**)&h->dec_ctl, sizeof(taco_dec_ctl) * h->dec_ctl_cap));

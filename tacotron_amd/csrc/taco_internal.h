@@ -99,6 +99,7 @@ struct taco_handle_s {
   size_t ws_gx_floats;
   taco_granule* enc_gran;    // encoder LSTM hand-off words
   size_t enc_gran_count;
+  int enc_group;             // utterances per launch of the encoder recurrence (0 = not worked out yet)
   taco_granule* dec_gran;    // decoder hand-off words, 2 parities
   taco_dec_layout dec_lay;
   taco_dec_ctl* dec_ctl;     // device, one block per utterance of a taco_decode call (grow-only)
@@ -127,7 +128,7 @@ int taco_launch_conv(const float* in, float* out, const float* w, const float* b
 int taco_conv_prepare();
 int taco_launch_enc_lstm(taco_handle h, const float* gx, const int32_t* lens, int B, int T, float* memory,
                          hipStream_t s);
-size_t taco_enc_lstm_granules();
+size_t taco_enc_lstm_granules(int n_cu);
 // Reads back the encoder's flags (the caller has synchronised the stream after copying them to
 // enc_ctl_host); clears them on the device when one is set.
 int taco_check_encoder_flags(taco_handle h, hipStream_t s);

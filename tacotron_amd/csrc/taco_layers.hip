@@ -216,7 +216,8 @@ __global__ __launch_bounds__(256) void taco_conv_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
-// Encoder BiLSTM recurrence, one utterance per launch.  The input projections W_ih x_t + b_ih + b_hh
+// Encoder BiLSTM recurrence, as many utterances per launch as fit the device at once (each with its own
+// workgroups and hand-off words; utterances never talk to each other).  The input projections W_ih x_t + b_ih + b_hh
 // of all steps are computed beforehand (a kernel-size-1 convolution); this kernel runs the sequential
 // part.  Few, fat workgroups: a hand-off between 9 workgroups is much cheaper than one between 65.
 // A workgroup of 1024 threads owns 32 hidden units of one direction = 128 gate rows, 8 lanes per row:
@@ -235,12 +236,12 @@ constexpr int EL_GRAN_DIR = 2 * EL_REP * EL_HMAX;   // granules per direction: 2
 
 struct EncLstmArgs {
   const float* w_hh[2];   // [4H][H]
-  const float* gx;        // [2][4H][T] this utterance
-  float* memory;          // [T][M] this utterance
+  const float* gx;        // [utterances][2][4H][T], first utterance of this launch
+  float* memory;          // [utterances][T][M], likewise
   const int32_t* lens;    // device, or NULL = T symbols
-  int b;                  // utterance index into lens
+  int b;                  // index of this launch's first utterance into lens
   int H, T, M, n_wg_dir;
-  taco_granule* gran;     // [2 dirs][2 parities][EL_REP][EL_HMAX]
+  taco_granule* gran;     // [utterances of a launch][2 dirs][2 parities][EL_REP][EL_HMAX]
   uint32_t* ctl;
 };
 
@@ -250,9 +251,11 @@ __global__ __launch_bounds__(1024) void taco_enc_lstm_kernel(const EncLstmArgs a
   __shared__ __attribute__((aligned(16))) float xh[EL_HMAX];
   __shared__ int gave_up;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int len = a.lens ? a.lens[a.b] : a.T;
-  const int dir = blockIdx.x / a.n_wg_dir;
-  const int jj = blockIdx.x % a.n_wg_dir;
+  const int utt = blockIdx.y;                      // utterance of this launch; blockIdx.x = direction, slice of units
+  const int wg = blockIdx.x;
+  const int len = a.lens ? min(a.lens[a.b + utt], a.T) : a.T;
+  const int dir = wg / a.n_wg_dir;
+  const int jj = wg % a.n_wg_dir;
   const int r = tid >> 3, part = tid & 7;          // gate row of this workgroup, 8 lanes per row
   const int unit = r >> 2, gate_id = r & 3;        // rows 4u..4u+3 = gates i, f, g, o of unit u
   const int gu = jj * EL_UNITS + unit;
@@ -274,12 +277,13 @@ __global__ __launch_bounds__(1024) void taco_enc_lstm_kernel(const EncLstmArgs a
   wctx.abort_word = (taco_gu32*)a.ctl;
   wctx.failed = 0;
   wctx.spun = 0;
-  taco_granule* gdir = a.gran + (size_t)dir * EL_GRAN_DIR;
-  const float* gx = a.gx + (size_t)dir * 4 * a.H * a.T;
+  taco_granule* gdir = a.gran + ((size_t)utt * 2 + dir) * EL_GRAN_DIR;
+  const float* gx = a.gx + ((size_t)utt * 2 + dir) * 4 * a.H * a.T;
+  float* memory = a.memory + (size_t)utt * a.T * a.M;
   const bool gate_lane = active && part == 0;      // finishes its row's gate
   const bool unit_lane = gate_lane && gate_id == 0;  // finishes its unit's cell update
   float cell = 0.0f;
-  const int my_rep = blockIdx.x % EL_REP;
+  const int my_rep = wg % EL_REP;
 
   for (int s = 0; s < len; ++s) {
     const int t = dir == 0 ? s : len - 1 - s;
@@ -294,13 +298,17 @@ __global__ __launch_bounds__(1024) void taco_enc_lstm_kernel(const EncLstmArgs a
       if (gave_up) break;
     }
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    // every chunk of the hidden vector is asked for before the first product: the reads' latency (not their
+    // number) is what this loop would otherwise wait for
+    float4 xv[KC];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) xv[k] = *reinterpret_cast<const float4*>(xh + 32 * k + 4 * part);
 #pragma unroll
     for (int k = 0; k < KC; ++k) {
-      const float4 x = *reinterpret_cast<const float4*>(xh + 32 * k + 4 * part);
-      acc[0] = fmaf(wr[k][0], x.x, acc[0]);
-      acc[1] = fmaf(wr[k][1], x.y, acc[1]);
-      acc[2] = fmaf(wr[k][2], x.z, acc[2]);
-      acc[3] = fmaf(wr[k][3], x.w, acc[3]);
+      acc[0] = fmaf(wr[k][0], xv[k].x, acc[0]);
+      acc[1] = fmaf(wr[k][1], xv[k].y, acc[1]);
+      acc[2] = fmaf(wr[k][2], xv[k].z, acc[2]);
+      acc[3] = fmaf(wr[k][3], xv[k].w, acc[3]);
     }
     const float pre = gx_v + taco_sum8((acc[0] + acc[1]) + (acc[2] + acc[3]));
     const float act = gate_id == 2 ? taco_tanh(pre) : taco_sigmoid(pre);     // valid in the row's lane 0
@@ -314,7 +322,7 @@ __global__ __launch_bounds__(1024) void taco_enc_lstm_kernel(const EncLstmArgs a
       cell = fg * cell + ig * gg;
       const float hv = og * taco_tanh(cell);
       taco_publish_rep<EL_REP>(gdir + (size_t)(s & 1) * EL_REP * EL_HMAX, EL_HMAX, gu, (unsigned)s + 1u, hv);
-      a.memory[(size_t)t * a.M + dir * a.H + gu] = hv;
+      memory[(size_t)t * a.M + dir * a.H + gu] = hv;
     }
     taco_lds_barrier();  // every thread is done with xh before the next step overwrites it (LDS only: the
                          // publish stores stay in flight)
@@ -480,28 +488,38 @@ int taco_launch_enc_lstm(taco_handle h, const float* gx, const int32_t* lens, in
   const int n_wg_dir = (d.H_e + EL_UNITS - 1) / EL_UNITS;
   if (d.H_e > EL_HMAX || 2 * n_wg_dir > h->n_cu)
     TACO_FAIL(TACO_EINVAL, "encoder LSTM width %d exceeds the recurrence kernel's capacity %d", d.H_e, EL_HMAX);
-  if (h->enc_gran_count < (size_t)2 * EL_GRAN_DIR) TACO_FAIL(TACO_EINVAL, "encoder hand-off buffer too small");
-  for (int b = 0; b < B; ++b) {
+  void (*kern)(EncLstmArgs) = d.H_e <= 128 ? taco_enc_lstm_kernel<4> : d.H_e <= 256 ? taco_enc_lstm_kernel<8>
+                              : d.H_e <= 384 ? taco_enc_lstm_kernel<12> : taco_enc_lstm_kernel<16>;
+  // Utterances per launch: all workgroups of a launch must be on the device together (the workgroups of an
+  // utterance wait for each other), so no more than the device holds at once.
+  if (h->enc_group < 1) {
+    int per_cu = 0;
+    TACO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 1024, 0));
+    if (per_cu < 1) TACO_FAIL(TACO_EINVAL, "encoder recurrence kernel does not fit on a CU");
+    h->enc_group = (h->n_cu * per_cu) / (2 * n_wg_dir);
+  }
+  const int cap = (int)(h->enc_gran_count / ((size_t)2 * EL_GRAN_DIR));
+  const int group = h->enc_group < cap ? h->enc_group : cap;
+  if (group < 1) TACO_FAIL(TACO_EINVAL, "encoder hand-off buffer too small");
+  for (int b0 = 0; b0 < B; b0 += group) {
+    const int n = B - b0 < group ? B - b0 : group;
     EncLstmArgs a;
     a.w_hh[0] = h->w.enc_lstm_w_hh[0];
     a.w_hh[1] = h->w.enc_lstm_w_hh[1];
-    a.gx = gx + (size_t)b * 8 * d.H_e * T;
-    a.memory = memory + (size_t)b * T * d.M;
-    a.lens = lens; a.b = b;
+    a.gx = gx + (size_t)b0 * 8 * d.H_e * T;
+    a.memory = memory + (size_t)b0 * T * d.M;
+    a.lens = lens; a.b = b0;
     a.H = d.H_e; a.T = T; a.M = d.M; a.n_wg_dir = n_wg_dir;
     a.gran = h->enc_gran; a.ctl = h->enc_ctl;
-    TACO_HIP(hipMemsetAsync(h->enc_gran, 0, h->enc_gran_count * sizeof(taco_granule), s));
-    const dim3 grid(2 * n_wg_dir), block(1024);
-    if (d.H_e <= 128) hipLaunchKernelGGL(taco_enc_lstm_kernel<4>, grid, block, 0, s, a);
-    else if (d.H_e <= 256) hipLaunchKernelGGL(taco_enc_lstm_kernel<8>, grid, block, 0, s, a);
-    else if (d.H_e <= 384) hipLaunchKernelGGL(taco_enc_lstm_kernel<12>, grid, block, 0, s, a);
-    else hipLaunchKernelGGL(taco_enc_lstm_kernel<16>, grid, block, 0, s, a);
+    TACO_HIP(hipMemsetAsync(h->enc_gran, 0, (size_t)n * 2 * EL_GRAN_DIR * sizeof(taco_granule), s));
+    hipLaunchKernelGGL(kern, dim3(2 * n_wg_dir, n), dim3(1024), 0, s, a);
     TACO_HIP(hipGetLastError());
   }
   return TACO_OK;
 }
 
-size_t taco_enc_lstm_granules() { return (size_t)2 * EL_GRAN_DIR; }
+// Hand-off words for as many utterances as a launch can hold: each needs at least two workgroups.
+size_t taco_enc_lstm_granules(int n_cu) { return (size_t)(n_cu > 2 ? n_cu / 2 : 1) * 2 * EL_GRAN_DIR; }
 
 int taco_launch_memory_tail(taco_handle h, const int64_t* speakers, const int32_t* lens, int B, int T,
                             float* memory, float* pm, hipStream_t s) {

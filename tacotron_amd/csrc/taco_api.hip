@@ -387,9 +387,20 @@ extern "C" int taco_decode(taco_handle h, const float* memory, const float* proc
   if (align) TACO_HIP(hipMemsetAsync(align, 0, sizeof(float) * (size_t)B * T_cap * T_in, s));
   // Utterances are independent; each one is a persistent launch of its own, enqueued back to back with no
   // host round trip in between.
+  // A padded batch wider than one folded-context chunk: the lengths come to the host (one small copy and wait per
+  // call) so that every utterance short enough runs the faster one-chunk instance; they are checked on the way.
+  std::vector<int32_t> host_lens;
+  if (lens && T_in > TACO_CHUNK) {
+    host_lens.resize((size_t)B);
+    TACO_HIP(hipMemcpyAsync(host_lens.data(), lens, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, s));
+    TACO_HIP(hipStreamSynchronize(s));
+    for (int b = 0; b < B; ++b)
+      if (host_lens[b] < 1 || host_lens[b] > T_in) TACO_FAIL(TACO_EINVAL, "taco_decode: lens[%d] = %d is outside 1..T_in=%d", b, host_lens[b], T_in);
+  }
   for (int b = 0; b < B; ++b) {
     const int rc = taco_launch_decoder(
-        h, memory + (size_t)b * T_in * d.M, processed_memory + (size_t)b * T_in * d.A, T_in, lens, b, masks, T_cap,
+        h, memory + (size_t)b * T_in * d.M, processed_memory + (size_t)b * T_in * d.A, T_in, lens, b,
+        host_lens.empty() ? T_in : host_lens[b], masks, T_cap,
         max_steps, gate_threshold, forced_mel ? forced_mel + (size_t)b * d.n_mel * T_cap : nullptr,
         mel + (size_t)b * d.n_mel * T_cap, gate + (size_t)b * T_cap, align ? align + (size_t)b * T_cap * T_in : nullptr,
         n_frames + b, reached_max + b, s);

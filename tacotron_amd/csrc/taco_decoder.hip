@@ -799,7 +799,7 @@ static unsigned long long* g_stamps_dev = nullptr;
 #endif
 
 int taco_launch_decoder(taco_handle h, const float* memory, const float* pm, int T_in, const int32_t* lens,
-                        int b, const uint8_t* masks, int T_cap, int max_steps, float thr, const float* forced_mel,
+                        int b, int own_len, const uint8_t* masks, int T_cap, int max_steps, float thr, const float* forced_mel,
                         float* mel, float* gate, float* align, int32_t* n_frames, uint8_t* reached,
                         hipStream_t s) {
   const taco_dims& d = h->d;
@@ -848,7 +848,9 @@ int taco_launch_decoder(taco_handle h, const float* memory, const float* pm, int
   if (b == 0) TACO_HIP(hipEventRecord(h->ev_start, s));
   const bool std_geom = d.P == 256 && d.R_a == 1024 && d.R_d == 1024 && d.A == 128 && d.F == 32 && d.K == 31 &&
                         d.n_mel == 80 && n_wg == 256;
-  const bool one_chunk = T_in <= TACO_CHUNK;     // all positions fit the first folded-context chunk
+  // own_len = this utterance's number of symbols as the host knows it (T_in when it does not): an utterance that
+  // fits the first folded-context chunk runs the one-chunk instance whatever the batch's padded width
+  const bool one_chunk = own_len <= TACO_CHUNK;
   auto kern = std_geom ? (one_chunk ? taco_decoder_kernel<true, 1> : taco_decoder_kernel<true, 2>)
                        : (one_chunk ? taco_decoder_kernel<false, 1> : taco_decoder_kernel<false, 2>);
   hipLaunchKernelGGL(kern, dim3(n_wg), dim3(NT), taco_decoder_lds_bytes(), s, a);

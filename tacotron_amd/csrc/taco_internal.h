@@ -137,7 +137,7 @@ int taco_launch_memory_tail(taco_handle h, const int64_t* speakers, const int32_
 int taco_launch_loc_fold(const float* dense_w, const float* conv_w, int A, int F, int K, int rows, float* out, hipStream_t s);
 int taco_launch_slice_cols(const float* src, int ld, int col0, int rows, int cols, float* dst, hipStream_t s);
 int taco_launch_decoder(taco_handle h, const float* memory, const float* pm, int T_in, const int32_t* lens,
-                        int b, const uint8_t* masks, int T_cap, int max_steps, float thr, const float* forced_mel,
+                        int b, int own_len, const uint8_t* masks, int T_cap, int max_steps, float thr, const float* forced_mel,
                         float* mel, float* gate, float* align, int32_t* n_frames, uint8_t* reached,
                         hipStream_t s);
 int taco_decoder_collect(taco_handle h, int B, hipStream_t s);

@@ -392,8 +392,8 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
       lds[LQ_ROWS + r * (TACO_NA * TACO_CHUNK) + c] = a.query_w[(size_t)(q_base + r) * Ra + c];
     }
     if (tid < q_cnt) lds[LQ_V + tid] = a.v_w[q_base + tid];
-    if (len <= LQ_PM_POS)
-      _Pragma("unroll 1") for (int k = tid; k < q_cnt * len; k += NT) {
+    if (NCTX == 1)
+      _Pragma("unroll 1") for (int k = tid; k < q_cnt * min(len, LQ_PM_POS); k += NT) {
         const int d = k % q_cnt, sp = k / q_cnt;
         lds[LQ_PM + d * LQ_PM_POS + sp] = a.pm[(size_t)sp * A + q_base + d];
       }
@@ -440,18 +440,11 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
     }
   }
   constexpr int LOC_UNROLL = (STD && NCTX == 1) ? LOC_KSTEPS : 2;   // as far as the instance's registers allow without spilling
+                                                                    // (4 and 8 measured slower in the two-chunk instance)
   auto update_location_term = [&]() {
     const int col = lane & 15, kq = lane >> 4;
-    _Pragma("unroll 1") for (int s0 = wave * 16; s0 < len; s0 += NW * 16) {
-      const int s = s0 + col;
-      // processed memory of this tile: LDS copy if the utterance fits, else from global memory (L2), asked for
-      // before the products so that the round trip runs beside them
-      float pmv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (len > LQ_PM_POS) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (s < len && 4 * kq + r < q_cnt) pmv[r] = a.pm[(size_t)s * A + q_base + 4 * kq + r];
-      }
+    // the products of one tile of 16 positions
+    auto tile_products = [&](int s0) -> taco_f32x4 {
       taco_f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll LOC_UNROLL
       for (int m = 0; m < LOC_KSTEPS; ++m) {
@@ -461,11 +454,31 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
         const float xv = lds[(c ? L_CUM : L_AW) + HALO + s0 + col + (ck - c * K) - pad];
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(lds[LQ_E + m * 64 + lane], xv, acc, 0, 0, 0);
       }
+      return acc;
+    };
+    if (NCTX == 1) {
+      // every position's processed memory is in LDS (the one-chunk instance runs inputs of up to LQ_PM_POS positions)
+      _Pragma("unroll 1") for (int s0 = wave * 16; s0 < len; s0 += NW * 16) {
+        const taco_f32x4 acc = tile_products(s0);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int d = 4 * kq + r;
-        if (len <= LQ_PM_POS) pmv[r] = lds[LQ_PM + d * LQ_PM_POS + s0 + col];
-        lds[LQ_U + d * TACO_MAX_TIN + s] = acc[r] + pmv[r];
+        for (int r = 0; r < 4; ++r) {
+          const int d = 4 * kq + r;
+          lds[LQ_U + d * TACO_MAX_TIN + s0 + col] = acc[r] + lds[LQ_PM + d * LQ_PM_POS + s0 + col];
+        }
+      }
+    } else {
+      // processed memory from global memory (L2), asked for before the products so that the round trip runs
+      // beside them.  (Keeping the first LQ_PM_POS positions in LDS and fetching only the rest, ahead of the
+      // other tiles, cost registers this instance does not have: it spilled and came out slower.)
+      _Pragma("unroll 1") for (int s0 = wave * 16; s0 < len; s0 += NW * 16) {
+        const int s = s0 + col;
+        float pmv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (s < len && 4 * kq + r < q_cnt) pmv[r] = a.pm[(size_t)s * A + q_base + 4 * kq + r];
+        const taco_f32x4 acc = tile_products(s0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lds[LQ_U + (4 * kq + r) * TACO_MAX_TIN + s] = acc[r] + pmv[r];
       }
     }
   };

@@ -441,7 +441,9 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
   }
   constexpr int LOC_UNROLL = (STD && NCTX == 1) ? LOC_KSTEPS : 2;   // as far as the instance's registers allow without spilling
                                                                     // (4 and 8 measured slower in the two-chunk instance)
-  auto update_location_term = [&]() {
+  // The two-chunk instance does the work in two passes (the wave's even and odd tiles), which a frame places in two
+  // different shadows; the one-chunk instance does everything in pass 0 (splitting it measured 0.1 us slower there).
+  auto update_location_term = [&](int pass) {
     const int col = lane & 15, kq = lane >> 4;
     // the products of one tile of 16 positions
     auto tile_products = [&](int s0) -> taco_f32x4 {
@@ -458,6 +460,7 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
     };
     if (NCTX == 1) {
       // every position's processed memory is in LDS (the one-chunk instance runs inputs of up to LQ_PM_POS positions)
+      if (pass != 0) return;
       _Pragma("unroll 1") for (int s0 = wave * 16; s0 < len; s0 += NW * 16) {
         const taco_f32x4 acc = tile_products(s0);
 #pragma unroll
@@ -470,7 +473,7 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
       // processed memory from global memory (L2), asked for before the products so that the round trip runs
       // beside them.  (Keeping the first LQ_PM_POS positions in LDS and fetching only the rest, ahead of the
       // other tiles, cost registers this instance does not have: it spilled and came out slower.)
-      _Pragma("unroll 1") for (int s0 = wave * 16; s0 < len; s0 += NW * 16) {
+      _Pragma("unroll 1") for (int s0 = (wave + NW * pass) * 16; s0 < len; s0 += 2 * NW * 16) {
         const int s = s0 + col;
         float pmv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -483,7 +486,7 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
     }
   };
   __syncthreads();
-  if (is_q) update_location_term();
+  if (is_q) { update_location_term(0); update_location_term(1); }
   __syncthreads();
   for (;; ++t) {
     const unsigned ep = (unsigned)t + 1u;
@@ -557,8 +560,10 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
     }
     if (t == a.max_steps) break;
     TACO_STAMP(0);
-    // Q group: this frame's location term from the previous frame's weights, while the P group works
-    if (is_q && t > 0) update_location_term();
+    // Q group: this frame's location term from the previous frame's weights; the first half of the tiles while the
+    // P group works, the second half after this workgroup's attention-LSTM values have left (a Q workgroup that
+    // arrives late at its attention-LSTM rows holds up every workgroup's gather of the hidden state)
+    if (is_q && t > 0) update_location_term(0);
     TACO_STAMP(1);
 
     // ============ S3: attention LSTM ============
@@ -587,6 +592,7 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
       if (st == 1) stopped = 1;
       if (st != 0) break;
     }
+    if (is_q && t > 0) update_location_term(1);
     // meanwhile: decoder-LSTM partial over the previous decoder hidden state
     float acc_d[2] = {0.0f, 0.0f};
     if (act_d) dot_chunks<TACO_ND>(wd[0] + TACO_NA + NCTX, wd[1] + TACO_NA + NCTX, lds + L_XDH, lane, acc_d);

@@ -406,6 +406,16 @@ def test_error_reporting():
   with pytest.raises(IndexError):
     gm.encode([dev(c) for c in chans(ids)], dev(bad_spk), None, validate=True)
   gm.encode([dev(c) for c in chans(ids)], dev(ids["speakers"]), None, validate=True)   # flags were cleared
+  # a padded batch wider than 256 positions: the lengths are read back and a length outside 1..T_in is refused
+  ck = scenario_checkpoint(meta["scenario"], meta["gate"])
+  wide = scenarios.random_ids(ck, [260, 12], seed=9)
+  lens_ok = dev(np.array([260, 12], np.int32))
+  mem_w, pm_w = gm.encode([dev(c) for c in chans(wide)], dev(wide["speakers"]), lens_ok)
+  for wrong in ([260, 0], [261, 12]):
+    with pytest.raises(TacoError):
+      gm.decode(mem_w, pm_w, dev(np.array(wrong, np.int32)), masks, 8)
+  out = gm.decode(mem_w, pm_w, lens_ok, masks, 8, gate_threshold=2.0)    # and the handle still works afterwards
+  assert out[3].cpu().tolist() == [8, 8]
 
 
 def test_synthesize_command_on_gpu_matches_oracle_backed_run(tmp_path):

@@ -144,9 +144,9 @@ int taco_encode(taco_handle h, const int64_t* const* ids, const int64_t* speaker
 /* Autoregressive decoder: all frames of all B utterances in one persistent launch.
  * Replaces Decoder.inference (reference: src/tacotron/model.py:529-568, 454-491, 96-117, 136-141).
  *   memory, processed_memory, lens   as produced by / passed to taco_encode
- *                (for batches wider than 256 positions the lengths are copied to the host once per call:
- *                each utterance short enough runs the faster kernel instance, and a length outside
- *                1..T_in is refused with TACO_EINVAL)
+ *                (the lengths are copied to the host once per call: a length outside 1..T_in is refused
+ *                with TACO_EINVAL, and in batches wider than 256 positions each utterance short enough
+ *                runs the faster kernel instance)
  *   masks        [T_cap, 2, P] uint8 (0 or 1): keep-masks of the two always-on prenet dropouts
  *                for frame t, layer 0/1, shared by all utterances; kept activations are scaled by 2
  *   max_steps    frames to produce at most, 1..T_cap (the reference's max_decoder_steps)

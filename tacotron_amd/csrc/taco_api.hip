@@ -387,10 +387,10 @@ extern "C" int taco_decode(taco_handle h, const float* memory, const float* proc
   if (align) TACO_HIP(hipMemsetAsync(align, 0, sizeof(float) * (size_t)B * T_cap * T_in, s));
   // Utterances are independent; each one is a persistent launch of its own, enqueued back to back with no
   // host round trip in between.
-  // A padded batch wider than one folded-context chunk: the lengths come to the host (one small copy and wait per
-  // call) so that every utterance short enough runs the faster one-chunk instance; they are checked on the way.
+  // The lengths of a padded batch come to the host (one small copy and wait per call): they are checked, and in a
+  // batch wider than one folded-context chunk every utterance short enough runs the faster one-chunk instance.
   std::vector<int32_t> host_lens;
-  if (lens && T_in > TACO_CHUNK) {
+  if (lens) {
     host_lens.resize((size_t)B);
     TACO_HIP(hipMemcpyAsync(host_lens.data(), lens, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, s));
     TACO_HIP(hipStreamSynchronize(s));

@@ -406,7 +406,7 @@ def test_error_reporting():
   with pytest.raises(IndexError):
     gm.encode([dev(c) for c in chans(ids)], dev(bad_spk), None, validate=True)
   gm.encode([dev(c) for c in chans(ids)], dev(ids["speakers"]), None, validate=True)   # flags were cleared
-  # a padded batch wider than 256 positions: the lengths are read back and a length outside 1..T_in is refused
+  # the lengths of a padded batch are read back and a length outside 1..T_in is refused
   ck = scenario_checkpoint(meta["scenario"], meta["gate"])
   wide = scenarios.random_ids(ck, [260, 12], seed=9)
   lens_ok = dev(np.array([260, 12], np.int32))

@@ -87,9 +87,11 @@ def _ptr(t: torch.Tensor):
 
 
 def bind_weights(hp: HParams, md: ModelDims, state: Dict[str, torch.Tensor],
-                 device: torch.device) -> Tuple[TacoWeights, List[torch.Tensor]]:
+                 device: torch.device, cdims: Optional[TacoDims] = None) -> Tuple[TacoWeights, List[torch.Tensor]]:
   """Returns the filled struct and the list of tensors whose storage it points into (keep the
-  list alive for as long as the pointers are used)."""
+  list alive for as long as the pointers are used).  With ``cdims`` (the extents handed to the
+  library) the embedding and speaker tables are checked against the row counts and widths the library
+  will copy, as the reference's ``load_state_dict`` would refuse a table of another shape."""
   keep: List[torch.Tensor] = []
 
   def get(key: str, shape: Tuple[int, ...]):
@@ -112,12 +114,16 @@ def bind_weights(hp: HParams, md: ModelDims, state: Dict[str, torch.Tensor],
     if not used:
       continue
     if is_table:
-      t = state[key]
-      w.ch_table[slot] = get(key, tuple(t.shape))
+      if key not in state:
+        raise KeyError(f"checkpoint model_state lacks '{key}'")
+      expect = tuple(state[key].shape) if cdims is None else (int(cdims.ch_rows[slot]), int(cdims.ch_width[slot]))
+      w.ch_table[slot] = get(key, expect)
     slot += 1
   if hp.use_speaker_embedding and hp.train_speaker_with_embedding:
-    t = state["speakers_embeddings.weight"]
-    w.spk_table = get("speakers_embeddings.weight", (t.shape[0], md.S))
+    if "speakers_embeddings.weight" not in state:
+      raise KeyError("checkpoint model_state lacks 'speakers_embeddings.weight'")
+    rows = state["speakers_embeddings.weight"].shape[0] if cdims is None else int(cdims.spk_rows)
+    w.spk_table = get("speakers_embeddings.weight", (rows, md.S))
 
   def conv_stack(prefix: str, n: int, cin0: int, cmid: int, cout_last: int, k: int, dst: str):
     for i in range(n):

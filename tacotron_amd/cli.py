@@ -350,12 +350,22 @@ def synthesize_ns(ns: argparse.Namespace, synthesizer_factory: Optional[Callable
     speaker = next(iter(speaker_mapping.keys())) if speaker_mapping else None
     log.debug(f"Speaker: {speaker}")
 
+  # The plan depends on which output files exist.  With several ranks it is made once, on rank 0, before any
+  # rank can have written a file, and handed to the others: ranks that planned for themselves could see each
+  # other's first outputs as "already synthesized" and disagree about the shards.
+  if n_ranks > 1:
+    import torch.distributed as dist
+    box = [plan_outputs(paragraphs, lines_to_infer, output_directory, ns.paragraph_directories, ns.prepend, ns.append,
+                        ns.overwrite, ns.include_stats, log) if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    plan = box[0]
+  else:
+    plan = plan_outputs(paragraphs, lines_to_infer, output_directory, ns.paragraph_directories, ns.prepend, ns.append,
+                        ns.overwrite, ns.include_stats, log)
+
   if synthesizer_factory is None:
     from tacotron_amd.synthesizer import Synthesizer as synthesizer_factory
   synth = synthesizer_factory(checkpoint, parse_hparams_string(ns.custom_hparams), device)
-
-  plan = plan_outputs(paragraphs, lines_to_infer, output_directory, ns.paragraph_directories, ns.prepend, ns.append,
-                      ns.overwrite, ns.include_stats, log)
   log.info("Inferring...")
   records = synthesize_plan(synth, plan, speaker, seed, ns.max_decoder_steps, ns.include_stats, ns.batch_size, group)
   if records is None:                        # not rank 0

@@ -164,6 +164,16 @@ extern "C" int taco_create(const taco_dims* dims, const taco_weights* weights, i
                                    w.proj_w, w.proj_b, w.gate_w, w.gate_b, w.post_conv_w[0]};
   for (const float* p : required)
     if (!p) { delete h; TACO_FAIL(TACO_EINVAL, "taco_create: a required weight pointer is NULL"); }
+  // ... and so must every per-layer tensor the layer counts call for
+  for (int l = 0; l < d.n_enc; ++l)
+    for (const float* p : {w.enc_conv_w[l], w.enc_conv_b[l], w.enc_bn_w[l], w.enc_bn_b[l], w.enc_bn_mean[l], w.enc_bn_var[l]})
+      if (!p) { delete h; TACO_FAIL(TACO_EINVAL, "taco_create: a tensor of encoder convolution %d is NULL", l); }
+  for (int dir = 0; dir < 2; ++dir)
+    for (const float* p : {w.enc_lstm_w_ih[dir], w.enc_lstm_w_hh[dir], w.enc_lstm_b_ih[dir], w.enc_lstm_b_hh[dir]})
+      if (!p) { delete h; TACO_FAIL(TACO_EINVAL, "taco_create: a tensor of the encoder LSTM (direction %d) is NULL", dir); }
+  for (int l = 0; l < d.n_post; ++l)
+    for (const float* p : {w.post_conv_w[l], w.post_conv_b[l], w.post_bn_w[l], w.post_bn_b[l], w.post_bn_mean[l], w.post_bn_var[l]})
+      if (!p) { delete h; TACO_FAIL(TACO_EINVAL, "taco_create: a tensor of postnet convolution %d is NULL", l); }
 
   // extra owned tensors: folded BatchNorm, stacked LSTM input weights and bias sums
   const size_t n_bn_enc = (size_t)d.n_enc * 2 * ((d.E + 63) / 64 * 64);
@@ -180,6 +190,12 @@ extern "C" int taco_create(const taco_dims* dims, const taco_weights* weights, i
   if (hipMalloc((void**)&h->pool, h->pool_floats * sizeof(float)) != hipSuccess) {
     delete h;
     TACO_FAIL(TACO_ENOMEM, "hipMalloc of %zu bytes for the weight pool failed", h->pool_floats * sizeof(float));
+  }
+  // Tensors are padded to 64 floats and some kernels read a ragged last slab past a row's end, relying on finite
+  // values there: the padding must not hold whatever bit patterns the allocation had before.
+  if (hipMemset(h->pool, 0, h->pool_floats * sizeof(float)) != hipSuccess) {
+    taco_destroy(h);
+    TACO_FAIL(TACO_EHIP, "hipMemset of the weight pool failed");
   }
 #define TACO_CREATE_HIP(call)                                                                          \
   do {                                                                                                 \
@@ -307,6 +323,7 @@ extern "C" int taco_encode(taco_handle h, const int64_t* const* ids, const int64
                            int32_t B, int32_t T_in, float* memory, float* processed_memory, void* stream) {
   if (!h || !ids || !memory || !processed_memory) TACO_FAIL(TACO_EINVAL, "taco_encode: NULL argument");
   if (B < 1 || T_in < 1) TACO_FAIL(TACO_EINVAL, "taco_encode: B = %d, T_in = %d", B, T_in);
+  if (T_in > TACO_MAX_TIN) TACO_FAIL(TACO_EINVAL, "taco_encode: T_in = %d symbols exceeds the decoder's capacity %d", T_in, TACO_MAX_TIN);
   hipStream_t s = (hipStream_t)stream;
   const taco_dims& d = h->d;
   DeviceScope on_device(h->device);
@@ -363,6 +380,10 @@ extern "C" int taco_decode(taco_handle h, const float* memory, const float* proc
   if (!h || !memory || !processed_memory || !masks || !mel || !gate || !n_frames || !reached_max)
     TACO_FAIL(TACO_EINVAL, "taco_decode: NULL argument");
   if (B < 1) TACO_FAIL(TACO_EINVAL, "taco_decode: B = %d", B);
+  // everything that sizes a memset or a launch is checked before anything is enqueued
+  if (T_in < 1 || T_in > TACO_MAX_TIN) TACO_FAIL(TACO_EINVAL, "taco_decode: T_in = %d symbols is outside the decoder's capacity 1..%d", T_in, TACO_MAX_TIN);
+  if (T_cap < 1) TACO_FAIL(TACO_EINVAL, "taco_decode: T_cap = %d", T_cap);
+  if (max_steps < 1 || max_steps > T_cap) TACO_FAIL(TACO_EINVAL, "taco_decode: max_steps %d outside 1..T_cap=%d", max_steps, T_cap);
   hipStream_t s = (hipStream_t)stream;
   const taco_dims& d = h->d;
   DeviceScope on_device(h->device);

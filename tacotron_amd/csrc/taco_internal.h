@@ -146,4 +146,3 @@ size_t taco_decoder_granules(int n_wg);
 void taco_decoder_fill_layout(taco_dec_layout* lay, int n_wg);
 int taco_decoder_check_dims(const taco_dims& d, int n_wg);
 int taco_decoder_prepare(taco_handle h);
-int taco_selftest_device(hipStream_t s);

@@ -60,7 +60,7 @@ class Tacotron2:
     if self._state is None:
       raise RuntimeError("load_state_dict must be called before moving the model to a device")
     self.close()
-    weights, keep = abi.bind_weights(self.hparams, self.dims, self._state, self.device)
+    weights, keep = abi.bind_weights(self.hparams, self.dims, self._state, self.device, self.cdims)
     handle = C.c_void_p()
     torch.cuda.synchronize(self.device)
     _lib.check(_lib.lib().taco_create(C.byref(self.cdims), C.byref(weights), self.device.index, C.byref(handle)))

@@ -18,7 +18,16 @@ def main():
   mode = sys.argv[1]
   if mode == "synthesize":
     ns = cli.build_parser().parse_args(sys.argv[1:])
-    ok = ns.handler(ns, synthesizer_factory=oracle_synthesizer)
+    slow_rank = os.environ.get("SHARD_WORKER_SLOW_RANK")
+
+    def factory(*args, **kwargs):
+      # one rank takes long to build its model: the others have written files by the time it goes on
+      if slow_rank is not None and int(os.environ.get("RANK", "0")) == int(slow_rank):
+        import time
+        time.sleep(3.0)
+      return oracle_synthesizer(*args, **kwargs)
+
+    ok = ns.handler(ns, synthesizer_factory=factory)
     rank, n = sharding.world()
     print(f"rank {rank}/{n} ok={ok}", flush=True)
     sys.exit(0 if ok else 1)

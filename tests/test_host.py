@@ -137,3 +137,24 @@ def test_model_refuses_cpu_device(gate_table):
     m.to("cpu")
   with pytest.raises(RuntimeError):
     m.step_weight_bytes
+
+
+def test_bind_weights_refuses_tables_of_another_shape(gate_table):
+  """The library copies ch_rows x ch_width floats from each table pointer: a checkpoint whose table is shorter
+  or narrower than the mappings call for must be refused on the host, as load_state_dict would refuse it
+  (reference: src/tacotron/training.py:762-768)."""
+  ck = scenario_checkpoint("tiny", gate_table["tiny"])
+  hp = ckpt_mod.get_hparams(ck)
+  counts = abi.mapping_counts(ck, hp)
+  cdims, md = abi.build_dims(hp, **counts)
+  cpu = torch.device("cpu")
+  abi.bind_weights(hp, md, ck["model_state"], cpu, cdims)          # the checkpoint as it is: accepted
+  short = dict(ck["model_state"])
+  short["symbol_embeddings.weight"] = short["symbol_embeddings.weight"][:-1]
+  with pytest.raises(ValueError):
+    abi.bind_weights(hp, md, short, cpu, cdims)
+  if "speakers_embeddings.weight" in ck["model_state"]:
+    narrow = dict(ck["model_state"])
+    narrow["speakers_embeddings.weight"] = narrow["speakers_embeddings.weight"][:, :-1]
+    with pytest.raises(ValueError):
+      abi.bind_weights(hp, md, narrow, cpu, cdims)

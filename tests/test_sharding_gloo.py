@@ -46,8 +46,8 @@ def _free_port():
     return s.getsockname()[1]
 
 
-def _launch(n, args, timeout=300):
-  env = dict(os.environ, OMP_NUM_THREADS="1", PYTHONPATH=ROOT)
+def _launch(n, args, timeout=300, extra_env=None):
+  env = dict(os.environ, OMP_NUM_THREADS="1", PYTHONPATH=ROOT, **(extra_env or {}))
   cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
          "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), WORKER] + args
   return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
@@ -70,6 +70,25 @@ def test_two_ranks_write_the_same_files_as_one(tmp_path):
   assert "rank 0/2 ok=True" in two.stdout and "rank 1/2 ok=True" in two.stdout
   names = sorted(p.name for p in (tmp_path / "one").iterdir())
   assert len(names) == 11 and names == sorted(p.name for p in (tmp_path / "two").iterdir())
+  for n in names:
+    np.testing.assert_array_equal(np.load(tmp_path / "one" / n), np.load(tmp_path / "two" / n))
+
+
+def test_a_slow_rank_plans_the_same_lines_without_overwrite(tmp_path):
+  """Without --overwrite a line whose output exists is skipped and does not advance the utterance counter.  A rank
+  that builds its model slowly must not take the files the fast rank has already written for existing outputs:
+  the plan is made once, before anybody writes."""
+  r = np.random.RandomState(9)
+  lines = ["|".join(f"s{r.randint(1, 31)}" for _ in range(r.randint(2, 9))) for _ in range(8)]
+  text = tmp_path / "in.txt"
+  text.write_text("\n".join(lines), encoding="UTF-8")
+  common = ["synthesize", TINY_CKPT, str(text), "--sep", "|", "--custom-seed", "5", "--max-decoder-steps", "10"]
+  one = _launch(1, common + ["-out", str(tmp_path / "one")])
+  assert one.returncode == 0, one.stdout + one.stderr
+  two = _launch(2, common + ["-out", str(tmp_path / "two")], extra_env={"SHARD_WORKER_SLOW_RANK": "1"})
+  assert two.returncode == 0, two.stdout + two.stderr
+  names = sorted(p.name for p in (tmp_path / "one").iterdir())
+  assert len(names) == 8 and names == sorted(p.name for p in (tmp_path / "two").iterdir())
   for n in names:
     np.testing.assert_array_equal(np.load(tmp_path / "one" / n), np.load(tmp_path / "two" / n))
 

@@ -2,6 +2,7 @@
 // of Tacotron2.inference - encode, decode, postnet - as enqueue-on-stream calls.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -186,7 +187,8 @@ extern "C" int taco_create(const taco_dims* dims, const taco_weights* weights, i
   const size_t n_fold = (size_t)fold_rows * 2 * d.K;
   h->pool_floats = plan.total + n_bn_enc + n_bn_post + (n_wcat + 63) / 64 * 64 + (n_bsum + 63) / 64 * 64 +
                    (n_ctxw + 63) / 64 * 64 + (n_fold + 63) / 64 * 64 + ((size_t)d.P * d.R_d + 63) / 64 * 64 +
-                   ((size_t)d.P + 63) / 64 * 64 + ((size_t)d.n_mel * d.R_d + 63) / 64 * 64;
+                   ((size_t)d.P + 63) / 64 * 64 + ((size_t)d.n_mel * d.R_d + 63) / 64 * 64 +
+                   ((size_t)d.P * d.M + 63) / 64 * 64 + ((size_t)d.n_mel * d.M + 63) / 64 * 64;
   if (hipMalloc((void**)&h->pool, h->pool_floats * sizeof(float)) != hipSuccess) {
     delete h;
     TACO_FAIL(TACO_ENOMEM, "hipMalloc of %zu bytes for the weight pool failed", h->pool_floats * sizeof(float));
@@ -254,6 +256,11 @@ extern "C" int taco_create(const taco_dims* dims, const taco_weights* weights, i
     rc = taco_launch_slice_cols(hw.proj_w, d.R_d + d.M, 0, d.n_mel, d.R_d, wp_h, 0);
     if (rc == TACO_OK) rc = taco_launch_conv(wp_h, h->wf_h, hw.prenet_w1, nullptr, nullptr, nullptr, nullptr, nullptr, 1, d.n_mel, d.P, 1, d.R_d, 0, 0, 0);
     if (rc == TACO_OK) rc = taco_launch_conv(hw.proj_b, h->wf_b, hw.prenet_w1, nullptr, nullptr, nullptr, nullptr, nullptr, 1, d.n_mel, d.P, 1, 1, 0, 0, 0);
+    // wf_c = W1 [P][n_mel] * Wp_c [n_mel][M]: the same fold for the projection's context columns (lockstep decoder)
+    h->wf_c = cur; cur += ((size_t)d.P * d.M + 63) / 64 * 64;
+    float* wp_c = cur; cur += ((size_t)d.n_mel * d.M + 63) / 64 * 64;
+    if (rc == TACO_OK) rc = taco_launch_slice_cols(hw.proj_w, d.R_d + d.M, d.R_d, d.n_mel, d.M, wp_c, 0);
+    if (rc == TACO_OK) rc = taco_launch_conv(wp_c, h->wf_c, hw.prenet_w1, nullptr, nullptr, nullptr, nullptr, nullptr, 1, d.n_mel, d.P, 1, d.M, 0, 0, 0);
     if (rc != TACO_OK) { taco_destroy(h); return rc; }
   }
   TACO_CREATE_HIP(hipGetLastError());
@@ -262,6 +269,13 @@ extern "C" int taco_create(const taco_dims* dims, const taco_weights* weights, i
   // ---- hand-off words, control blocks, events ----
   taco_decoder_fill_layout(&h->dec_lay, h->n_cu);
   TACO_CREATE_HIP(hipMalloc((void**)&h->dec_gran, taco_decoder_granules(h->n_cu) * sizeof(taco_granule)));
+  h->bat_ok = taco_decoder_batch_supported(d, h->n_cu);
+  if (h->bat_ok) {
+    taco_decoder_batch_fill_layout(&h->bat_lay);
+    TACO_CREATE_HIP(hipMalloc((void**)&h->bat_gran, taco_decoder_batch_granules() * sizeof(taco_granule)));
+    rc = taco_decoder_batch_prepare(h);
+    if (rc != TACO_OK) { taco_destroy(h); return rc; }
+  }
   h->enc_gran_count = taco_enc_lstm_granules(h->n_cu);
   TACO_CREATE_HIP(hipMalloc((void**)&h->enc_gran, h->enc_gran_count * sizeof(taco_granule)));
   h->dec_ctl_cap = 64;
@@ -291,6 +305,7 @@ extern "C" int taco_destroy(taco_handle h) {
   if (h->ws_G) (void)hipFree(h->ws_G);
   if (h->enc_gran) (void)hipFree(h->enc_gran);
   if (h->dec_gran) (void)hipFree(h->dec_gran);
+  if (h->bat_gran) (void)hipFree(h->bat_gran);
   if (h->dec_ctl) (void)hipFree(h->dec_ctl);
   if (h->enc_ctl) (void)hipFree(h->enc_ctl);
   if (h->dec_ctl_host) (void)hipHostFree(h->dec_ctl_host);
@@ -418,16 +433,45 @@ extern "C" int taco_decode(taco_handle h, const float* memory, const float* proc
     for (int b = 0; b < B; ++b)
       if (host_lens[b] < 1 || host_lens[b] > T_in) TACO_FAIL(TACO_EINVAL, "taco_decode: lens[%d] = %d is outside 1..T_in=%d", b, host_lens[b], T_in);
   }
+  // Which decoder runs what.  Utterances of up to TACO_BT_TIN symbols go, sixteen at a time in the caller's order,
+  // through the lockstep kernel (one persistent launch per group); a lone utterance and the long ones run the
+  // batch-1 kernel, one launch each.  TACO_DECODER=single / lockstep in the environment forces one of them
+  // (lockstep still only for utterances within its capacity).
+  int min_group = 2;
+  if (const char* mode = getenv("TACO_DECODER")) {
+    if (mode[0] == 's') min_group = 1 << 30;
+    else if (mode[0] == 'l') min_group = 1;
+  }
+  std::vector<int> fits;
+  std::vector<int> rest;
   for (int b = 0; b < B; ++b) {
+    const int own = host_lens.empty() ? T_in : host_lens[b];
+    if (h->bat_ok && own <= TACO_BT_TIN) fits.push_back(b);
+    else rest.push_back(b);
+  }
+  if ((int)fits.size() < min_group) {
+    rest.insert(rest.end(), fits.begin(), fits.end());
+    fits.clear();
+  }
+  int n_launches = 0;
+  for (size_t i0 = 0; i0 < fits.size(); i0 += TACO_BATCH_NB) {
+    const int n = (int)(fits.size() - i0 < (size_t)TACO_BATCH_NB ? fits.size() - i0 : TACO_BATCH_NB);
+    const int rc = taco_launch_decoder_batch(h, memory, processed_memory, T_in, lens, fits.data() + i0, n, n_launches, masks, T_cap,
+                                             max_steps, gate_threshold, forced_mel, mel, gate, align, n_frames, reached_max, s);
+    if (rc != TACO_OK) return rc;
+    ++n_launches;
+  }
+  for (int b : rest) {
     const int rc = taco_launch_decoder(
-        h, memory + (size_t)b * T_in * d.M, processed_memory + (size_t)b * T_in * d.A, T_in, lens, b,
+        h, memory + (size_t)b * T_in * d.M, processed_memory + (size_t)b * T_in * d.A, T_in, lens, b, n_launches,
         host_lens.empty() ? T_in : host_lens[b], masks, T_cap,
         max_steps, gate_threshold, forced_mel ? forced_mel + (size_t)b * d.n_mel * T_cap : nullptr,
         mel + (size_t)b * d.n_mel * T_cap, gate + (size_t)b * T_cap, align ? align + (size_t)b * T_cap * T_in : nullptr,
         n_frames + b, reached_max + b, s);
     if (rc != TACO_OK) return rc;
+    ++n_launches;
   }
-  return taco_decoder_collect(h, B, s);
+  return taco_decoder_collect(h, n_launches, s);
 }
 
 extern "C" int taco_postnet(taco_handle h, const float* mel, const int32_t* n_frames, int32_t B, int32_t T_cap,

@@ -818,7 +818,7 @@ static unsigned long long* g_stamps_dev = nullptr;
 #endif
 
 int taco_launch_decoder(taco_handle h, const float* memory, const float* pm, int T_in, const int32_t* lens,
-                        int b, int own_len, const uint8_t* masks, int T_cap, int max_steps, float thr, const float* forced_mel,
+                        int b, int launch_idx, int own_len, const uint8_t* masks, int T_cap, int max_steps, float thr, const float* forced_mel,
                         float* mel, float* gate, float* align, int32_t* n_frames, uint8_t* reached,
                         hipStream_t s) {
   const taco_dims& d = h->d;
@@ -838,8 +838,8 @@ int taco_launch_decoder(taco_handle h, const float* memory, const float* pm, int
   a.pm = pm; a.G = h->ws_G; a.masks = masks; a.T_cap = T_cap; a.max_steps = max_steps; a.thr = thr;
   a.shift_energies = h->energy_bound > 64.0f ? 1 : 0;
   a.forced_mel = forced_mel; a.mel = mel; a.gate = gate; a.align = align; a.n_frames_out = n_frames; a.reached_out = reached;
-  a.gran = h->dec_gran; a.lay = h->dec_lay; a.ctl = h->dec_ctl + b;
-  a.frame_clock = b == 0 ? h->frame_clock : nullptr;
+  a.gran = h->dec_gran; a.lay = h->dec_lay; a.ctl = h->dec_ctl + launch_idx;
+  a.frame_clock = launch_idx == 0 ? h->frame_clock : nullptr;
   a.frame_clock_cap = h->frame_clock_cap;
 
   // folded context weights of this utterance: G = ctx_w_cat [rows][M] * memory^T [M][T_in], run as a
@@ -864,7 +864,7 @@ int taco_launch_decoder(taco_handle h, const float* memory, const float* pm, int
   TACO_HIP(hipMemsetAsync(g_stamps_dev, 0, stamp_count * 8, s));
   a.stamps = g_stamps_dev;
 #endif
-  if (b == 0) TACO_HIP(hipEventRecord(h->ev_start, s));
+  if (launch_idx == 0) TACO_HIP(hipEventRecord(h->ev_start, s));
   const bool std_geom = d.P == 256 && d.R_a == 1024 && d.R_d == 1024 && d.A == 128 && d.F == 32 && d.K == 31 &&
                         d.n_mel == 80 && n_wg == 256;
   // own_len = this utterance's number of symbols as the host knows it (T_in when it does not): an utterance that
@@ -879,7 +879,8 @@ int taco_launch_decoder(taco_handle h, const float* memory, const float* pm, int
 
 // After the last utterance of a taco_decode call has been enqueued: one wait for the whole batch, then
 // the control blocks (and what a preceding taco_encode on this stream found) are checked.
-int taco_decoder_collect(taco_handle h, int B, hipStream_t s) {
+int taco_decoder_collect(taco_handle h, int n_launches, hipStream_t s) {
+  const int B = n_launches;
   TACO_HIP(hipEventRecord(h->ev_stop, s));
   h->timing_valid = 1;
   TACO_HIP(hipMemcpyAsync(h->dec_ctl_host, h->dec_ctl, sizeof(taco_dec_ctl) * (size_t)B, hipMemcpyDeviceToHost, s));
@@ -893,7 +894,7 @@ int taco_decoder_collect(taco_handle h, int B, hipStream_t s) {
   for (int b = 0; b < B; ++b) {
     const taco_dec_ctl& c = h->dec_ctl_host[b];
     if (c.abort_code != 0)
-      TACO_FAIL(TACO_ETIMEDOUT, "decoder hand-off wait gave up (utterance %d, code %u, info 0x%x) after %u frames", b,
+      TACO_FAIL(TACO_ETIMEDOUT, "decoder hand-off wait gave up (launch %d of the call, code %u, info 0x%x) after %u frames", b,
                 c.abort_code, c.abort_info, c.n_frames);
     if ((int)c.n_frames > longest) longest = (int)c.n_frames;
   }

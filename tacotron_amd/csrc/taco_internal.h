@@ -58,6 +58,23 @@ struct taco_dec_layout {
   int32_t per_parity;                            // granules per parity block
 };
 
+// ---- the lockstep (batched) decoder: capacities and hand-off layout ----
+constexpr int TACO_BATCH_NB = 16;       // utterances per lockstep launch = columns of one matrix-core tile
+constexpr int TACO_BT_KP = 256;         // k capacity of the prenet vectors
+constexpr int TACO_BT_KH = 1024;        // ... of the LSTM hidden states
+constexpr int TACO_BT_KC = 576;         // ... of the attention context (M <= 8 * TACO_BT_MEMW = 544)
+constexpr int TACO_BT_TIN = 256;        // symbols per utterance
+constexpr int TACO_BT_MEMW = 68;        // memory columns per Q workgroup
+constexpr int TACO_BT_ROWS = 16;        // rows per P / M workgroup
+#ifndef TACO_BT_REP
+#define TACO_BT_REP 2                   // replicas of every all-to-all vector
+#endif
+struct taco_bat_layout {                // granule offsets inside one parity block; vectors are [utterance][k]
+  int32_t h1, p, ah, pe, ctx, dh, stop;
+  int32_t h1_cap, p_cap, ah_cap, ctx_cap, dh_cap, stop_cap;   // replica strides
+  int32_t per_parity;
+};
+
 struct taco_dec_ctl {      // device-visible control block (zeroed before every launch)
   uint32_t abort_code;     // first failure code raised by any workgroup (0 = none)
   uint32_t abort_info;     // vector id / frame of the failed wait
@@ -91,6 +108,7 @@ struct taco_handle_s {
   // Prenet layer 1 folded into the mel projection: wf_h [P][R_d] = W1 * linear_projection[:, :R_d], wf_b [P] = W1 * bias
   float* wf_h;
   float* wf_b;
+  float* wf_c;               // [P][M] = W1 * linear_projection[:, R_d:] (the lockstep decoder's explicit context columns)
   float* ws_G;               // [ctx_rows][T_in] folded context weights G = ctx_w_cat * memory^T
   // workspaces (grow-only)
   float* ws_act[2];          // activation ping-pong [B][C_max][T]
@@ -102,7 +120,10 @@ struct taco_handle_s {
   int enc_group;             // utterances per launch of the encoder recurrence (0 = not worked out yet)
   taco_granule* dec_gran;    // decoder hand-off words, 2 parities
   taco_dec_layout dec_lay;
-  taco_dec_ctl* dec_ctl;     // device, one block per utterance of a taco_decode call (grow-only)
+  taco_granule* bat_gran;    // lockstep decoder hand-off words, 2 parities (NULL when the model exceeds its capacities)
+  taco_bat_layout bat_lay;
+  int bat_ok;                // the lockstep kernel can run this model
+  taco_dec_ctl* dec_ctl;     // device, one block per launch of a taco_decode call (grow-only)
   taco_dec_ctl* dec_ctl_host;  // pinned host mirror
   int dec_ctl_cap;
   uint32_t* enc_ctl;         // device: [0] abort code, [1] abort info of the encoder LSTM kernel, [2] 1 + channel of an
@@ -137,10 +158,20 @@ int taco_launch_memory_tail(taco_handle h, const int64_t* speakers, const int32_
 int taco_launch_loc_fold(const float* dense_w, const float* conv_w, int A, int F, int K, int rows, float* out, hipStream_t s);
 int taco_launch_slice_cols(const float* src, int ld, int col0, int rows, int cols, float* dst, hipStream_t s);
 int taco_launch_decoder(taco_handle h, const float* memory, const float* pm, int T_in, const int32_t* lens,
-                        int b, int own_len, const uint8_t* masks, int T_cap, int max_steps, float thr, const float* forced_mel,
+                        int b, int launch_idx, int own_len, const uint8_t* masks, int T_cap, int max_steps, float thr, const float* forced_mel,
                         float* mel, float* gate, float* align, int32_t* n_frames, uint8_t* reached,
                         hipStream_t s);
-int taco_decoder_collect(taco_handle h, int B, hipStream_t s);
+int taco_decoder_collect(taco_handle h, int n_launches, hipStream_t s);
+// lockstep decoder (taco_decoder_batch.hip)
+int taco_launch_decoder_batch(taco_handle h, const float* memory, const float* pm, int T_in, const int32_t* lens,
+                              const int* utt, int n, int launch_idx, const uint8_t* masks, int T_cap, int max_steps, float thr,
+                              const float* forced_mel, float* mel, float* gate, float* align, int32_t* n_frames,
+                              uint8_t* reached, hipStream_t s);
+size_t taco_decoder_batch_lds_bytes();
+size_t taco_decoder_batch_granules();
+void taco_decoder_batch_fill_layout(taco_bat_layout* lay);
+int taco_decoder_batch_supported(const taco_dims& d, int n_wg);
+int taco_decoder_batch_prepare(taco_handle h);
 size_t taco_decoder_lds_bytes();
 size_t taco_decoder_granules(int n_wg);
 void taco_decoder_fill_layout(taco_dec_layout* lay, int n_wg);

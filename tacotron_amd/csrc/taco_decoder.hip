@@ -879,6 +879,9 @@ int taco_launch_decoder(taco_handle h, const float* memory, const float* pm, int
 
 // After the last utterance of a taco_decode call has been enqueued: one wait for the whole batch, then
 // the control blocks (and what a preceding taco_encode on this stream found) are checked.
+#ifdef TACO_BT_STAMPS
+void taco_decoder_batch_dump_stamps(int n_frames);
+#endif
 int taco_decoder_collect(taco_handle h, int n_launches, hipStream_t s) {
   const int B = n_launches;
   TACO_HIP(hipEventRecord(h->ev_stop, s));
@@ -899,7 +902,7 @@ int taco_decoder_collect(taco_handle h, int n_launches, hipStream_t s) {
     if ((int)c.n_frames > longest) longest = (int)c.n_frames;
   }
 #ifdef TACO_STAMPS
-  {
+  if (g_stamps_dev) {
     const size_t stamp_count = (size_t)(4 + TACO_NQ_WG) * TACO_STAMP_FRAMES * TACO_STAMP_POINTS;
     std::vector<unsigned long long> st(stamp_count);
     TACO_HIP(hipMemcpy(st.data(), g_stamps_dev, stamp_count * 8, hipMemcpyDeviceToHost));
@@ -974,6 +977,9 @@ int taco_decoder_collect(taco_handle h, int n_launches, hipStream_t s) {
       for (int k = 1; k < 6; ++k) fprintf(stderr, "  %-32s %7.2f\n", qn[k], acc[k] / cnt);
     }
   }
+#endif
+#ifdef TACO_BT_STAMPS
+  taco_decoder_batch_dump_stamps(longest);
 #endif
   h->last_frames = longest;
   return TACO_OK;

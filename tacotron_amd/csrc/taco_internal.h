@@ -59,11 +59,13 @@ struct taco_dec_layout {
 };
 
 // ---- the lockstep (batched) decoder: capacities and hand-off layout ----
+constexpr int TACO_BT_THREADS = 256;    // 4 waves: the LSTM rows fill most of the CU's register file
+constexpr int TACO_BT_WGS = 256;        // workgroups of a launch: 4 hidden units of each cell per workgroup
 constexpr int TACO_BATCH_NB = 16;       // utterances per lockstep launch = columns of one matrix-core tile
 constexpr int TACO_BT_KP = 256;         // k capacity of the prenet vectors
 constexpr int TACO_BT_KH = 1024;        // ... of the LSTM hidden states
 constexpr int TACO_BT_KC = 576;         // ... of the attention context (M <= 8 * TACO_BT_MEMW = 544)
-constexpr int TACO_BT_TIN = 256;        // symbols per utterance
+constexpr int TACO_BT_TIN = 208;        // symbols per utterance (what the Q workgroups' LDS has room for)
 constexpr int TACO_BT_MEMW = 68;        // memory columns per Q workgroup
 constexpr int TACO_BT_ROWS = 16;        // rows per P / M workgroup
 #ifndef TACO_BT_REP

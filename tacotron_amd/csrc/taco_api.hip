@@ -272,8 +272,10 @@ extern "C" int taco_create(const taco_dims* dims, const taco_weights* weights, i
   h->bat_ok = taco_decoder_batch_supported(d, h->n_cu);
   if (h->bat_ok) {
     taco_decoder_batch_fill_layout(&h->bat_lay);
-    TACO_CREATE_HIP(hipMalloc((void**)&h->bat_gran, taco_decoder_batch_granules() * sizeof(taco_granule)));
+    TACO_CREATE_HIP(hipMalloc((void**)&h->bat_gran, taco_decoder_batch_handoff_bytes()));
+    TACO_CREATE_HIP(hipMalloc((void**)&h->bat_wstream, taco_decoder_batch_wstream_floats() * sizeof(float)));
     rc = taco_decoder_batch_prepare(h);
+    if (rc == TACO_OK) rc = taco_decoder_batch_pack(h);
     if (rc != TACO_OK) { taco_destroy(h); return rc; }
   }
   h->enc_gran_count = taco_enc_lstm_granules(h->n_cu);
@@ -306,6 +308,7 @@ extern "C" int taco_destroy(taco_handle h) {
   if (h->enc_gran) (void)hipFree(h->enc_gran);
   if (h->dec_gran) (void)hipFree(h->dec_gran);
   if (h->bat_gran) (void)hipFree(h->bat_gran);
+  if (h->bat_wstream) (void)hipFree(h->bat_wstream);
   if (h->dec_ctl) (void)hipFree(h->dec_ctl);
   if (h->enc_ctl) (void)hipFree(h->enc_ctl);
   if (h->dec_ctl_host) (void)hipHostFree(h->dec_ctl_host);

@@ -9,23 +9,29 @@
 // caller seeds every line alike, reference: src/tacotron_cli/inference.py:137-141, 241).
 //
 // Why lockstep: at batch 1 a frame is a chain of cross-CU hand-offs of about a microsecond each with
-// little work in between, and the matrix cores idle.  The hand-offs cost the same whether they carry
-// one utterance or sixteen, and sixteen utterances turn every weight row's dot product into a column
-// of a 16 x 16 tile: the LSTM gate rows become v_mfma_f32_16x16x4_f32 products (exact f32).
+// little work in between, and the matrix cores idle.  The hand-offs' latency is the same whether they
+// carry one utterance or sixteen, and sixteen utterances turn every weight row's dot product into a
+// column of a 16 x 16 tile: the LSTM gate rows become v_mfma_f32_16x16x4_f32 products (exact f32).
 //
-// Layout of the work (one workgroup of 512 threads per CU, resident for the whole launch):
+// Layout of the work (one workgroup of 256 threads per CU, resident for the whole launch; four waves,
+// one per SIMD, so that each may use its SIMD's whole register file):
 //   * every workgroup j owns hidden units 4j..4j+3 of both LSTM cells = 16 gate rows each.  The rows
-//     stay in registers as MFMA A operands for the whole launch, split over the 8 waves by columns
-//     (wave w holds a 1/8 slice of every row); a wave's partial 16 x 16 tile meets the other waves'
-//     in LDS, wave 0 adds them, applies the cell update for its 4 units x 16 utterances (one per lane)
-//     and publishes the hidden values;
-//   * activations travel as 8-byte {epoch, fp32} granules, utterance-major ([utterance][k]), and are
-//     loaded straight into MFMA B operands: lane (utterance u = l & 15, q = l >> 4) fetches 16 bytes =
-//     the two granules k = 8 p + 2 q, +1 of pair p, which are its operands of two consecutive 4-deep
-//     steps (the weights are held in the same column order);
+//     stay in registers as MFMA A operands for the whole launch (280 per lane, most of them in the
+//     accumulation half of the file), split over the 4 waves by columns; a wave's partial 16 x 16 tile
+//     meets the other waves' in LDS, wave 0 adds them, applies the cell update for its 4 units x 16
+//     utterances (one per lane) and publishes the hidden values;
+//   * what bounds a frame is how fast every CU can take in everybody's activations (each of the 256 CUs
+//     needs every hidden value of every utterance), so an exchanged value is 4 bytes, not a {tag, value}
+//     pair: an fp32 whose two lowest mantissa bits carry the generation of its slot (1 or 2, alternating
+//     between the uses of a slot; 0 = never written).  The consumer uses the word as it is - tag bits
+//     included, a relative perturbation of at most 2^-22, the same for everyone - and checks the tag
+//     bits of what it loaded.  Vectors are utterance-major ([utterance][k]) and are loaded straight into
+//     MFMA B operands: lane (utterance u = l & 15, q = l >> 4) fetches 16 bytes = the words
+//     k = 16 i + 4 q .. + 3 of load i, its operands of four consecutive 4-deep steps (the weights are held
+//     in the same column order).  Every vector is fetched once per workgroup and frame;
 //   * the attention context is computed explicitly (the batch-1 kernel folds it into per-utterance
 //     weight rows, which a batch cannot share): 8 "Q" workgroups per utterance each hold 16 attention
-//     dimensions (query rows, location filter, processed memory) and an eighth of the memory columns;
+//     dimensions (query rows, location filter, location term) and an eighth of the memory columns;
 //     they exchange partial energies among themselves, each runs the softmax, and each publishes its
 //     columns of the context;
 //   * prenet layer 1 is folded into the mel projection, W1 (Wp [dh ; ctx] + b) = (W1 Wp) [dh ; ctx] + W1 b,
@@ -34,9 +40,11 @@
 //     (16 projection / stop-token rows each) write the frame beside the dependency chain.  Both read
 //     their rows from LDS as MFMA A operands and share the B operands of the LSTM loads.
 // A frame's chain: dh, ctx -> h1 (P) -> p (P) -> attention LSTM (all) -> ah -> energies (Q) -> partial
-// energies (Q to Q) -> softmax, context (Q) -> ctx -> decoder LSTM (all) -> dh.
+// energies (Q to Q) -> softmax, context (Q) -> ctx -> decoder LSTM (all) -> dh.  Products that nobody
+// waits for (next frame's attention-LSTM columns, the recurrent columns) run in the shadows of the hops.
 // An utterance that has stopped keeps its slot (its values stay finite and are no longer written out);
-// the launch ends when every utterance has stopped or max_steps frames have been produced.
+// empty slots of a group run as copies of its first utterance; the launch ends when every utterance has
+// stopped or max_steps frames have been produced.
 #include "taco_device.h"
 
 #include <math.h>
@@ -46,32 +54,34 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) unsigned int bt_gword;
 
-constexpr int NT = TACO_BT_THREADS;     // 4 waves, one per SIMD: each may use the SIMD's whole register file (512 per lane)
+constexpr int NT = TACO_BT_THREADS;
 constexpr int NW = NT / 64;
 constexpr int NB = TACO_BATCH_NB;
 static_assert(NW == 4, "softmax and query reductions are written for 4 waves");
 static_assert(NB == 16, "one utterance per column of a 16 x 16 matrix-core tile");
-// k capacities of the exchanged vectors: multiples of 64 = 8 waves x (pairs of 4-deep steps)
+// k capacities of the exchanged vectors: multiples of 64 = 4 waves x (16-byte loads of 4 words x 4 lane quarters)
 constexpr int KP = TACO_BT_KP, KH = TACO_BT_KH, KC = TACO_BT_KC;
-constexpr int NPW_P = KP / 8 / NW;     // pairs of k-steps per wave: 8
-constexpr int NPW_H = KH / 8 / NW;     // 32
-constexpr int NPW_C = KC / 8 / NW;     // 18
-constexpr int HCH = 8;                 // pairs per load burst of the long vectors
-constexpr int TIN = TACO_BT_TIN;       // positions per utterance (256)
+constexpr int NL_P = KP / 16 / NW;     // 16-byte loads per wave and lane: 4   (4 k-steps each)
+constexpr int NL_H = KH / 16 / NW;     // 16
+constexpr int NL_C = KC / 16 / NW;     // 9
+constexpr int BURST = 4;               // loads checked together
+constexpr int TIN = TACO_BT_TIN;       // positions per utterance
 constexpr int HALO = 16;
 constexpr int QD = 16;                 // attention dimensions per Q workgroup
 constexpr int NQ = TACO_NQ_WG;         // Q workgroups per utterance (8)
 constexpr int MEMW = TACO_BT_MEMW;     // memory columns per Q workgroup (68)
-constexpr int CQ = TACO_BT_MEMW / 4;   // column quads of a memory slice (17)
+constexpr int CQ = MEMW / 4;           // column quads of a memory slice (17)
 constexpr int CPG = 15;                // position groups of the context sum (15 x 17 threads)
-constexpr int QT = (TACO_BT_TIN / 16 + NW - 1) / NW;   // tiles of 16 positions per wave (4: wave w takes tiles w, w + 4, ...)
+constexpr int QT = (TIN / 16 + NW - 1) / NW;   // tiles of 16 positions per wave (wave w takes tiles w, w + 4, ...)
 constexpr int QR = 16 / NW;            // query rows per wave (4)
 constexpr int LOC_KSTEPS = 16;
 constexpr int RP = TACO_BT_ROWS;       // rows per P / M workgroup (one MFMA tile)
 constexpr int W1_KSTEPS = (TACO_MAX_MEL + 3) / 4;    // 20
 static_assert(2 * TACO_MAX_K <= 4 * LOC_KSTEPS, "location taps fit 16 steps of 4");
-static_assert(QR == 4 && CPG * CQ <= NT && MEMW % 4 == 0 && NQ * MEMW >= 544, "context sum thread map");
+static_assert(QR == 4 && QT % 2 == 0 && CPG * CQ <= NT && MEMW % 4 == 0 && NQ * MEMW >= 544, "Q thread maps");
+static_assert(NL_H % BURST == 0 && NL_P == BURST, "burst structure");
 
 // ---- LDS carve (float offsets) ----
 constexpr int L_RED = 0;                         // [4 waves][64 lanes][4]: partial tiles of an LSTM stage
@@ -92,9 +102,9 @@ constexpr int LM_W = L_ROLE;
 constexpr int LM_RED = LM_W + KS_HC * 64;
 constexpr int LM_BIAS = LM_RED + NW * 256;
 constexpr int LM_END = LM_BIAS + RP;
-// Q: query rows [16][1024], memory slice [256][68], location filter [16][64], hidden state of my utterance /
+// Q: query rows [16][1024], memory slice [positions][68], location filter [16][64], hidden state of my utterance /
 //    gathered partial energies / context partial sums (one area, used one after the other), weights and
-//    cumulative weights with halos, query values, unnormalised weights, softmax scratch
+//    cumulative weights with halos, query values, softmax scratch, location term [positions][16]
 constexpr int LQ_ROWS = L_ROLE;
 constexpr int LQ_MEM = LQ_ROWS + QD * KH;
 constexpr int LQ_E = LQ_MEM + TIN * MEMW;
@@ -103,7 +113,7 @@ constexpr int LQ_AW = LQ_XPE + NQ * TIN;
 constexpr int LQ_CUM = LQ_AW + TIN + 2 * HALO;
 constexpr int LQ_Q = LQ_CUM + TIN + 2 * HALO;
 constexpr int LQ_SRED = LQ_Q + QD;
-constexpr int LQ_U = LQ_SRED + 32;               // location term + processed memory [position][16 dimensions]
+constexpr int LQ_U = LQ_SRED + 32;
 constexpr int LQ_END = LQ_U + TIN * QD;
 static_assert(NQ * TIN >= KH && NQ * TIN >= CPG * MEMW, "shared Q scratch area");
 constexpr int L_TOTAL = LP_END > LQ_END ? (LP_END > LM_END ? LP_END : LM_END) : (LQ_END > LM_END ? LQ_END : LM_END);
@@ -116,6 +126,7 @@ struct BatArgs {
   const int32_t* lens;     // device, or NULL = T_in symbols each
   const float *prenet_w1, *prenet_w2, *wf_h, *wf_c, *wf_b, *att_w_ih, *att_w_hh, *att_b_ih, *att_b_hh, *query_w, *v_w,
       *loc_fold, *dec_w_ih, *dec_w_hh, *dec_b_ih, *dec_b_hh, *proj_w, *proj_b, *gate_w, *gate_b;
+  const float4* wstream;   // attention-LSTM input columns re-packed per (workgroup, wave, load, lane): see taco_bt_pack_kernel
   const float* memory;     // [B][T_in][M]
   const float* pm;         // [B][T_in][A]
   const uint8_t* masks;
@@ -126,8 +137,8 @@ struct BatArgs {
   float *mel, *gate, *align;
   int32_t* n_frames;
   uint8_t* reached;
-  taco_granule* gran;
-  unsigned gran_bytes;
+  uint32_t* words;         // hand-off memory, two parity blocks
+  unsigned words_bytes;
   taco_bat_layout lay;
   taco_dec_ctl* ctl;
   unsigned long long* frame_clock;
@@ -148,108 +159,78 @@ constexpr int BT_STAMP_FRAMES = 256, BT_STAMP_POINTS = 16;
 #define BT_STAMP(k) do {} while (0)
 #endif
 
-// B operands come straight from the hand-off words: lane (utterance u = l & 15, q = l >> 4) fetches 16 bytes = the two
-// granules {payload, epoch} x 2 of a pair.  Every granule of every vector is published every frame (padding beyond
-// a vector's true length as zeros, empty utterance slots as copies of utterance 0), so the check is uniform: all
-// tags must carry the epoch.  bt_issue starts a burst of NPAIR such loads, bt_finish checks it and, when a tag is
-// not there yet, fetches the burst again after a short sleep (one compact loop per burst: after the nap the values
-// are there at the first attempt as a rule).  Issuing the next burst before finishing the current one keeps the
-// memory round trip beside the matrix products.
-template <int NPAIR>
-__device__ __forceinline__ void bt_issue(__amdgpu_buffer_rsrc_t rs, unsigned gidx, u32x4 (&v)[NPAIR]) {
-#pragma unroll
-  for (int i = 0; i < NPAIR; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (gidx + 8u * i) * 8u, 0, 16 /* sc1 */);
-}
-template <int NPAIR>
-__device__ __forceinline__ void bt_finish(__amdgpu_buffer_rsrc_t rs, unsigned gidx, unsigned ep, u32x4 (&v)[NPAIR],
-                                          float (&b)[2 * NPAIR], taco_wait_ctx& ctx, unsigned info) {
-  unsigned spins = 0;
-  for (;;) {
-    unsigned bad = 0;
-#pragma unroll
-    for (int i = 0; i < NPAIR; ++i) bad |= (v[i].y ^ ep) | (v[i].w ^ ep);
-    if (__all(bad == 0u) || ctx.failed) break;
-    ctx.spun = 1;
-    __builtin_amdgcn_s_sleep(TACO_POLL_SLEEP);
-    if ((++spins & 255u) == 0u) {
-      if (__hip_atomic_load(ctx.abort_word, TACO_RLX_AGENT) != 0u) { ctx.failed = 1; break; }
-      if (spins >= TACO_SPIN_LIMIT) {
-        __hip_atomic_store(ctx.abort_word, TACO_ABORT_TIMEOUT, TACO_RLX_AGENT);
-        __hip_atomic_store(ctx.abort_word + 1, info, TACO_RLX_AGENT);
-        ctx.failed = 1;
-        break;
-      }
-    }
-    asm volatile("" ::: "memory");
-    bt_issue<NPAIR>(rs, gidx, v);
-  }
-#pragma unroll
-  for (int i = 0; i < NPAIR; ++i) {
-    b[2 * i] = __uint_as_float(v[i].x);
-    b[2 * i + 1] = __uint_as_float(v[i].z);
-  }
-}
-template <int NPAIR>
-__device__ __forceinline__ void bt_load_pairs(__amdgpu_buffer_rsrc_t rs, unsigned gidx, unsigned ep, float (&b)[2 * NPAIR],
-                                              taco_wait_ctx& ctx, unsigned info) {
-  u32x4 v[NPAIR];
-  bt_issue<NPAIR>(rs, gidx, v);
-  bt_finish<NPAIR>(rs, gidx, ep, v, b, ctx, info);
-}
-
-// Gathers up to NPT pairs of granules per thread into LDS as plain floats (Q workgroups: the hidden state and the
-// partial energies of their own utterance).  src[i] = granule index of the pair, dst[i] = LDS float index, n = pairs in use.
-template <int NPT>
-__device__ __forceinline__ void bt_gather_pairs(__amdgpu_buffer_rsrc_t rs, const unsigned (&src)[NPT], const int (&dst)[NPT], int n,
-                                                unsigned ep, float* lds, taco_wait_ctx& ctx, unsigned info) {
-  u32x4 v[NPT];
-  unsigned spins = 0;
-  for (;;) {
-#pragma unroll
-    for (int i = 0; i < NPT; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, src[i] * 8u, 0, 16 /* sc1 */);
-    unsigned bad = 0;
-#pragma unroll
-    for (int i = 0; i < NPT; ++i)
-      if (i < n) bad |= (v[i].y ^ ep) | (v[i].w ^ ep);
-    if (__all(bad == 0u) || ctx.failed) break;
-    ctx.spun = 1;
-    __builtin_amdgcn_s_sleep(TACO_POLL_SLEEP);
-    if ((++spins & 255u) == 0u) {
-      if (__hip_atomic_load(ctx.abort_word, TACO_RLX_AGENT) != 0u) { ctx.failed = 1; break; }
-      if (spins >= TACO_SPIN_LIMIT) {
-        __hip_atomic_store(ctx.abort_word, TACO_ABORT_TIMEOUT, TACO_RLX_AGENT);
-        __hip_atomic_store(ctx.abort_word + 1, info, TACO_RLX_AGENT);
-        ctx.failed = 1;
-        break;
-      }
-    }
-    asm volatile("" ::: "memory");
-  }
-#pragma unroll
-  for (int i = 0; i < NPT; ++i)
-    if (i < n) *reinterpret_cast<float2*>(lds + dst[i]) = make_float2(__uint_as_float(v[i].x), __uint_as_float(v[i].z));
-}
-
 // An LDS index behind a compiler barrier.  The carve of a Q workgroup reaches far past the 64 KB an LDS instruction's
 // immediate offset covers, so the compiler forms one address register per access, finds them all loop-invariant and
 // hoists them out of the frame loop - dozens of registers this kernel does not have (they ended up in scratch memory).
 // An index made opaque inside the frame is recomputed there (one or two vector operations) and the accesses near it
 // become immediate offsets from it.
 #define BT_OPQ(expr) ({ int v_ = (expr); asm volatile("" : "+v"(v_)); v_; })
+#define BT_SB() __builtin_amdgcn_sched_barrier(0)
 
-template <int N>
-__device__ __forceinline__ f32x4 bt_mfma_regs(const float (&w)[N], const float (&b)[N], f32x4 acc) {
+// ---- tagged words ----
+__device__ __forceinline__ unsigned bt_tagged(float value, unsigned tag) { return (__float_as_uint(value) & ~3u) | tag; }
+// One value to all R replicas of a vector (replica stride `cap` words): atomic exchanges whose result is dropped,
+// carried out at the memory side.
+template <int R>
+__device__ __forceinline__ void bt_publish(uint32_t* base, int cap, int idx, unsigned tag, float value) {
+  const unsigned word = bt_tagged(value, tag);
 #pragma unroll
-  for (int i = 0; i < N; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i], b[i], acc, 0, 0, 0);
-  return acc;
+  for (int r = 0; r < R; ++r) (void)__hip_atomic_exchange((bt_gword*)base + (size_t)r * cap + idx, word, TACO_RLX_AGENT);
 }
-// A operands from LDS ([k-step][lane] floats)
-template <int N>
-__device__ __forceinline__ f32x4 bt_mfma_lds(const float* w_lds, int lane, const float (&b)[N], f32x4 acc) {
+
+// Four consecutive words (16-byte aligned word index widx) to all R replicas with write-through 16-byte stores: every
+// word carries its own tag, so nothing depends on the 16 bytes landing together.  (One 16-byte store per four values
+// instead of four memory-side atomics: a frame publishes some 80 000 words chip-wide.)
+template <int R>
+__device__ __forceinline__ void bt_store4(__amdgpu_buffer_rsrc_t rs, unsigned widx, int cap, unsigned tag, float v0, float v1, float v2,
+                                          float v3) {
+  const u32x4 w = {bt_tagged(v0, tag), bt_tagged(v1, tag), bt_tagged(v2, tag), bt_tagged(v3, tag)};
 #pragma unroll
-  for (int i = 0; i < N; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w_lds[i * 64 + lane], b[i], acc, 0, 0, 0);
-  return acc;
+  for (int r = 0; r < R; ++r) __builtin_amdgcn_raw_buffer_store_b128(w, rs, (widx + (unsigned)(r * cap)) * 4u, 0, 16 /* sc1 */);
 }
+// A hidden value per lane (lane = utterance + 16 * unit) -> the lanes of unit 0 collect their utterance's four units
+// and store them as one 16-byte piece at word index `widx` (= vector offset + utterance * K + 4 * workgroup).
+template <int R>
+__device__ __forceinline__ void bt_publish_units(__amdgpu_buffer_rsrc_t rs, unsigned widx, int cap, unsigned tag, float hv, int lane) {
+  const float h1 = __shfl(hv, (lane & 15) + 16, 64), h2 = __shfl(hv, (lane & 15) + 32, 64), h3 = __shfl(hv, (lane & 15) + 48, 64);
+  if (lane < 16) bt_store4<R>(rs, widx, cap, tag, hv, h1, h2, h3);
+}
+
+// B operands come straight from the hand-off words.  bt_issue starts N 16-byte loads (word index widx + 16 i),
+// bt_check looks at the tag bits of loads [i0, i0 + CNT) and, while one is not there yet, fetches those loads again
+// after a short sleep (after the nap the values are there at the first attempt as a rule).  All loads of a vector are
+// issued at once and checked burst by burst, so the memory round trips run beside the matrix products.
+template <int N>
+__device__ __forceinline__ void bt_issue(__amdgpu_buffer_rsrc_t rs, unsigned widx, u32x4 (&v)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (widx + 16u * i) * 4u, 0, 16 /* sc1 */);
+}
+template <int N, int I0, int CNT>
+__device__ __forceinline__ void bt_check(__amdgpu_buffer_rsrc_t rs, unsigned widx, unsigned tag, u32x4 (&v)[N], taco_wait_ctx& ctx,
+                                         unsigned info) {
+  unsigned spins = 0;
+  for (;;) {
+    unsigned bad = 0;
+#pragma unroll
+    for (int i = I0; i < I0 + CNT; ++i) bad |= (v[i].x ^ tag) | (v[i].y ^ tag) | (v[i].z ^ tag) | (v[i].w ^ tag);
+    if (__all((bad & 3u) == 0u) || ctx.failed) break;
+    ctx.spun = 1;
+    __builtin_amdgcn_s_sleep(TACO_POLL_SLEEP);
+    if ((++spins & 255u) == 0u) {
+      if (__hip_atomic_load(ctx.abort_word, TACO_RLX_AGENT) != 0u) { ctx.failed = 1; break; }
+      if (spins >= TACO_SPIN_LIMIT) {
+        __hip_atomic_store(ctx.abort_word, TACO_ABORT_TIMEOUT, TACO_RLX_AGENT);
+        __hip_atomic_store(ctx.abort_word + 1, info, TACO_RLX_AGENT);
+        ctx.failed = 1;
+        break;
+      }
+    }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = I0; i < I0 + CNT; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (widx + 16u * i) * 4u, 0, 16);
+  }
+}
+#define BT_F(x) __uint_as_float(x)
 
 // The waves' partial tiles -> LDS at float index `red`; after the barrier wave 0 holds the sum (other waves get their own
 // partial back).
@@ -273,18 +254,18 @@ __device__ __forceinline__ float bt_lstm_cell(f32x4 pre, f32x4 bias, float& c) {
   return og * taco_tanh(c);
 }
 
-template <int R>
-__device__ __forceinline__ void bt_publish(taco_granule* base, int cap, int idx, unsigned epoch, float value) {
-  const taco_granule word = ((taco_granule)epoch << 32) | (taco_granule)__float_as_uint(value);
-#pragma unroll
-  for (int r = 0; r < R; ++r) taco_send((taco_ggran*)base + (size_t)r * cap + idx, word);
-}
-
 __device__ __forceinline__ void bt_nap_begin(int nap, taco_wait_ctx& ctx) {
   taco_nap(nap);
   ctx.spun = 0;
   asm volatile("" ::: "memory");
 }
+
+// 4 k-steps of one load against 4 weight registers: two independent accumulation chains
+#define BT_MFMA4(W, i, V, accA, accB)                                                              \
+  accA = __builtin_amdgcn_mfma_f32_16x16x4f32(W[4 * (i) + 0], BT_F(V.x), accA, 0, 0, 0);           \
+  accB = __builtin_amdgcn_mfma_f32_16x16x4f32(W[4 * (i) + 1], BT_F(V.y), accB, 0, 0, 0);           \
+  accA = __builtin_amdgcn_mfma_f32_16x16x4f32(W[4 * (i) + 2], BT_F(V.z), accA, 0, 0, 0);           \
+  accB = __builtin_amdgcn_mfma_f32_16x16x4f32(W[4 * (i) + 3], BT_F(V.w), accB, 0, 0, 0);
 
 __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(const BatArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -304,7 +285,6 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
   const int n_p_wg = KP / RP;                             // rows beyond P have zero weights and publish zeros
   const int n_m_wg = (NMEL + 1 + RP - 1) / RP;
   const int qd = (A + NQ - 1) / NQ;                       // attention dimensions per Q workgroup (<= 16)
-  const int n_dg = NQ;                                    // every group runs (one without dimensions contributes zeros)
   const int q_off = n_p_wg + n_m_wg;
   const bool is_p = j < n_p_wg;
   const bool is_m = j >= n_p_wg && j < q_off;
@@ -314,46 +294,43 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
   const int dg = is_q ? q_id % NQ : 0;
   const int q_b = a.utt[q_slot];                          // my utterance (Q)
   const int len = is_q ? (a.lens ? min(a.lens[q_b], a.T_in) : a.T_in) : 0;
-  const int len4 = (len + 3) & ~3;
   const int q_base = dg * qd;
   const int q_cnt = is_q ? max(0, min(qd, A - q_base)) : 0;
-  const int cw = (M + NQ - 1) / NQ;                       // memory columns per Q workgroup (<= MEMW)
+  const int cw = MEMW;                                    // memory columns per Q workgroup (the last ones may lie beyond M: zeros)
   const int c0 = dg * cw;
   const int c_cnt = is_q ? max(0, min(cw, M - c0)) : 0;    // memory columns I hold (I publish cw: the rest are zeros)
   const bool forced = a.forced_mel != nullptr;
   const int pad = (K - 1) / 2;
 
   // ---------------- one-time loads: LSTM rows as A operands in registers ----------------
-  // A operand of lane l: row (l & 15) = 4 * unit + gate of the workgroup's 16 rows, column k of step i:
-  // k = 8 * (pair) + 2 * (l >> 4) + (i & 1), pair = wave * pairs_per_wave + (i >> 1)
+  // (228 of the 280 per lane.  The attention LSTM's prenet and context columns - 52 - are read from a re-packed copy in
+  // global memory every frame instead, L2-resident and asked for well before they are used: with them the rows would not
+  // leave the vector half of the register file to everything else, and the compiler spilled rows to scratch memory.)
+  // A operand of lane l: row (l & 15) = 4 * unit + gate of the workgroup's 16 rows, column k of step s of a vector's
+  // wave slice: k = 16 * (wave * loads_per_wave + (s >> 2)) + 4 * (l >> 4) + (s & 3)
   const int row16 = lane & 15;
   const int hid_a = j * 4 + (row16 >> 2), gate_a = row16 & 3;
   const bool own_a = hid_a < Ra, own_d = hid_a < Rd;
   const size_t ra = (size_t)gate_a * Ra + hid_a, rd = (size_t)gate_a * Rd + hid_a;
-  float wa_p[2 * NPW_P], wa_c[2 * NPW_C], wa_h[2 * NPW_H];
-  float wd_a[2 * NPW_H], wd_c[2 * NPW_C], wd_h[2 * NPW_H];
-#define BT_K(NPW, i) (8 * (wave * (NPW) + ((i) >> 1)) + 2 * kq + ((i) & 1))
+  float wa_h[4 * NL_H];
+  float wd_a[4 * NL_H], wd_c[4 * NL_C], wd_h[4 * NL_H];
+#define BT_K(NL, s) (16 * (wave * (NL) + ((s) >> 2)) + 4 * kq + ((s) & 3))
 #pragma unroll
-  for (int i = 0; i < 2 * NPW_P; ++i) {
-    const int k = BT_K(NPW_P, i);
-    wa_p[i] = (own_a && k < P) ? a.att_w_ih[ra * (P + M) + k] : 0.0f;
-  }
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int i = 0; i < 2 * NPW_C; ++i) {
-    const int k = BT_K(NPW_C, i);
-    wa_c[i] = (own_a && k < M) ? a.att_w_ih[ra * (P + M) + P + k] : 0.0f;
+  for (int i = 0; i < 4 * NL_C; ++i) {
+    const int k = BT_K(NL_C, i);
     wd_c[i] = (own_d && k < M) ? a.dec_w_ih[rd * (Ra + M) + Ra + k] : 0.0f;
+    if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
   }
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int i = 0; i < 2 * NPW_H; ++i) {
-    const int k = BT_K(NPW_H, i);
+  for (int i = 0; i < 4 * NL_H; ++i) {
+    const int k = BT_K(NL_H, i);
     wa_h[i] = (own_a && k < Ra) ? a.att_w_hh[ra * Ra + k] : 0.0f;
     wd_a[i] = (own_d && k < Ra) ? a.dec_w_ih[rd * (Ra + M) + k] : 0.0f;
     wd_h[i] = (own_d && k < Rd) ? a.dec_w_hh[rd * Rd + k] : 0.0f;
     if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
   }
+#undef BT_K
   if (tid < NB) reinterpret_cast<int*>(lds + L_UTT)[tid] = a.utt[tid];
   if (tid < 16) {     // biases as [unit][gate]
     const int u = tid >> 2, gt = tid & 3, hu = j * 4 + u;
@@ -362,8 +339,8 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
   }
 
   // ---------------- one-time loads of the roles ----------------
-  // A operands kept in LDS as [global k-step][lane]: k-step ks of a vector's wave slice, lane l -> row l & 15,
-  // column k as above.  Global k-steps of [dh ; ctx]: dh 0..255 (wave w: 32 w ..), ctx 256..399 (wave w: 256 + 18 w ..).
+  // A operands kept in LDS as [global k-step][lane]: k-step ks = 4 * load + e, lane l -> row l & 15,
+  // column k = 16 * load + 4 * (l >> 4) + e.  Global k-steps of [dh ; ctx]: dh 0..255, ctx 256..399.
   const int n_hc = Rd + M;
   if (is_p || is_m) {
     float* dst = lds + (is_p ? LP_WF : LM_W);
@@ -374,11 +351,11 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
       float v = 0.0f;
       if (r < n_rows) {
         if (ks < KH / 4) {
-          const int k = 8 * (ks >> 1) + 2 * q4 + (ks & 1);
+          const int k = 16 * (ks >> 2) + 4 * q4 + (ks & 3);
           if (k < Rd) v = is_p ? a.wf_h[(size_t)r * Rd + k] : (r < NMEL ? a.proj_w[(size_t)r * n_hc + k] : a.gate_w[k]);
         } else {
           const int kc = ks - KH / 4;
-          const int k = 8 * (kc >> 1) + 2 * q4 + (kc & 1);
+          const int k = 16 * (kc >> 2) + 4 * q4 + (kc & 3);
           if (k < M) v = is_p ? a.wf_c[(size_t)r * M + k] : (r < NMEL ? a.proj_w[(size_t)r * n_hc + Rd + k] : a.gate_w[Rd + k]);
         }
       }
@@ -393,12 +370,12 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
   if (is_p) {
     _Pragma("unroll 1") for (int e = tid; e < (KP / 4) * 64; e += NT) {
       const int ks = e >> 6, l = e & 63;
-      const int r = j * RP + (l & 15), k = 8 * (ks >> 1) + 2 * (l >> 4) + (ks & 1);
+      const int r = j * RP + (l & 15), k = 16 * (ks >> 2) + 4 * (l >> 4) + (ks & 3);
       lds[LP_W2 + e] = (r < P && k < P) ? a.prenet_w2[(size_t)r * P + k] : 0.0f;
     }
     _Pragma("unroll 1") for (int e = tid; e < W1_KSTEPS * 64; e += NT) {
       const int ks = e >> 6, l = e & 63;
-      const int r = j * RP + (l & 15), k = 8 * (ks >> 1) + 2 * (l >> 4) + (ks & 1);
+      const int r = j * RP + (l & 15), k = 16 * (ks >> 2) + 4 * (l >> 4) + (ks & 3);
       lds[LP_W1 + e] = (r < P && k < NMEL) ? a.prenet_w1[(size_t)r * NMEL + k] : 0.0f;
     }
   }
@@ -429,7 +406,7 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
   wctx.failed = 0;
   wctx.spun = 0;
   int nap_h1 = 0, nap_p = 0, nap_ahq = 0, nap_ah = 0, nap_pe = 0, nap_ctx = 0, nap_dh = 0;
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.gran, 0, (int)a.gran_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.words, 0, (int)a.words_bytes, 0x00020000);
 
   // Q: the location term of my tiles, U = processed memory + sum over taps of E * {previous, cumulative} weights.
   // Lane (position col = l & 15, kq): dimensions 4 kq .. + 3 of the tile's 16 x 16 result; the B operand of 4-tap step m
@@ -458,9 +435,7 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
       }
     }
   }
-  // (lane_o: the lane number behind a compiler barrier, taken anew every frame.  Every address below derives from it, so
-  // none of them is loop-invariant: hoisted out of the frame loop, the 16 + 16 per-step addresses would sit in
-  // registers - or, with the LSTM rows filling the register file, in scratch memory - for the whole launch.)
+  // (lane_o: the lane number behind a compiler barrier, taken anew every frame, see BT_OPQ.)
   auto update_location_term = [&](int lane_o) {
     const int col = lane_o & 15, kqo = lane_o >> 4;
     const int x_base = BT_OPQ(LQ_AW + HALO + col + kqo - pad);     // LDS index of tap kq at position 0 (previous weights)
@@ -493,13 +468,13 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
 #pragma unroll
         for (int gq = 0; gq < LOC_KSTEPS / 4; ++gq) {
           if (gq + 1 < LOC_KSTEPS / 4) read_group(gq + 1, ev[(gq + 1) & 1], x0[(gq + 1) & 1], x1[(gq + 1) & 1]);
-          __builtin_amdgcn_sched_barrier(0);
+          BT_SB();
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ev[gq & 1][i], x0[gq & 1][i], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ev[gq & 1][i], x1[gq & 1][i], acc1, 0, 0, 0);
           }
-          __builtin_amdgcn_sched_barrier(0);
+          BT_SB();
         }
         *reinterpret_cast<float4*>(u_lane + s0 * QD) = make_float4(acc0[0] + pm0[0], acc0[1] + pm0[1], acc0[2] + pm0[2], acc0[3] + pm0[3]);
         if (s1 < len)
@@ -507,11 +482,11 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
       }
     }
   };
-  // Q: what each thread gathers.  Hidden state of my utterance: pairs tid, tid + 256 of its 512.  Partial energies:
-  // thread (group tid >> 5, l = tid & 31) takes pairs l, l + 32, l + 64, l + 96 of that group's positions.
+  // Q: partial energies are gathered by thread (group tid >> 5, l = tid & 31): pairs of granules l, l + 32, l + 64, l + 96
+  // of that group's positions
   const int len16 = (len + 15) & ~15;
   const int pe_n = max(0, min(4, (len16 / 2 - (tid & 31) + 31) / 32));
-  const unsigned pe_src0 = (unsigned)(a.lay.pe + (q_slot * NQ + (tid >> 5)) * TIN + 2 * (tid & 31));
+  const unsigned pe_src0 = (unsigned)(a.lay.pe + 2 * ((q_slot * NQ + (tid >> 5)) * TIN + 2 * (tid & 31)));   // word index
 
   f32x4 acc_a = {0.0f, 0.0f, 0.0f, 0.0f};     // attention-LSTM partial over [context ; hidden] of the previous frame
   f32x4 acc_dn = {0.0f, 0.0f, 0.0f, 0.0f};    // decoder-LSTM partial over the previous decoder hidden state
@@ -519,70 +494,29 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
   unsigned alive = a.n_utts >= 32 ? 0xffffffffu : ((1u << a.n_utts) - 1u);
   int my_frames = 0;                           // thread tid < 16 of every workgroup: frames of utterance slot tid
   int t = 0;
-  // granule index of this lane's first pair in each vector, replica `rep`
-  const unsigned g_lane_p = (unsigned)(rep * a.lay.p_cap + utt * KP + 8 * (wave * NPW_P) + 2 * kq);
-  const unsigned g_lane_h = (unsigned)(rep * a.lay.ah_cap + utt * KH + 8 * (wave * NPW_H) + 2 * kq);
-  const unsigned g_lane_c = (unsigned)(rep * a.lay.ctx_cap + utt * KC + 8 * (wave * NPW_C) + 2 * kq);
+  // word index of this lane's first load in each vector, replica `rep`
+  const unsigned w_lane_h1 = (unsigned)(a.lay.h1 + rep * a.lay.h1_cap + utt * KP + 16 * (wave * NL_P) + 4 * kq);
+  const unsigned w_lane_p = (unsigned)(a.lay.p + rep * a.lay.p_cap + utt * KP + 16 * (wave * NL_P) + 4 * kq);
+  const unsigned w_lane_ah = (unsigned)(a.lay.ah + rep * a.lay.ah_cap + utt * KH + 16 * (wave * NL_H) + 4 * kq);
+  const unsigned w_lane_dh = (unsigned)(a.lay.dh + rep * a.lay.dh_cap + utt * KH + 16 * (wave * NL_H) + 4 * kq);
+  const unsigned w_lane_c = (unsigned)(a.lay.ctx + rep * a.lay.ctx_cap + utt * KC + 16 * (wave * NL_C) + 4 * kq);
+  const float4* ws_lane = a.wstream + ((size_t)(j * NW + wave) * (NL_P + NL_C)) * 64 + lane;   // load i: ws_lane[i * 64]
   unsigned keep_next = 0;                      // P, wave 0: keep bytes of my 4 rows, layer 0 (low) / layer 1 of the coming frame
   unsigned keep_l1 = 0, keep_l2 = 0;
   if (is_p && wave == 0) {
     const int r0 = j * RP + 4 * kq;
-    if (r0 < P) {
-      keep_l2 = *reinterpret_cast<const unsigned*>(a.masks + P + r0);              // frame 0, layer 2
-    }
-  }
-
-  // A stream of the bursts of HCH pairs of this lane's slice of one hidden-state vector, double-buffered: BODY(ch, b) sees
-  // burst ch's 2 * HCH operands.  PRE(ch) runs after the next burst has been issued and before this one is waited for (LDS
-  // reads of A operands go there).  The scheduling barriers pin the order issue-next / wait-current / products: left to
-  // itself the compiler, short of registers, moves the next burst's wait in among this burst's products.
-#define BT_SB() __builtin_amdgcn_sched_barrier(0)
-#define BT_STREAM_H(base_, info_, ADJ, PRE, BODY)                                                  \
-  {                                                                                                \
-    u32x4 va[HCH], vb[HCH];                                                                        \
-    const unsigned base = (base_);                                                                 \
-    bt_issue<HCH>(rs, base, va);                                                                   \
-    BT_SB();                                                                                       \
-    _Pragma("unroll") for (int ch = 0; ch < NPW_H / HCH; ch += 2) {                                \
-      bt_issue<HCH>(rs, base + 8u * HCH * (ch + 1), vb);                                           \
-      BT_SB();                                                                                     \
-      {                                                                                            \
-        float b[2 * HCH];                                                                          \
-        PRE(ch);                                                                                   \
-        bt_finish<HCH>(rs, base + 8u * HCH * ch, ep, va, b, wctx, info_);                          \
-        if (ch == 0) { ADJ; }                                                                      \
-        BT_SB();                                                                                   \
-        BODY(ch, b);                                                                               \
-        BT_SB();                                                                                   \
-      }                                                                                            \
-      if (ch + 2 < NPW_H / HCH) {                                                                  \
-        bt_issue<HCH>(rs, base + 8u * HCH * (ch + 2), va);                                         \
-        BT_SB();                                                                                   \
-      }                                                                                            \
-      {                                                                                            \
-        float b[2 * HCH];                                                                          \
-        PRE(ch + 1);                                                                               \
-        bt_finish<HCH>(rs, base + 8u * HCH * (ch + 1), ep, vb, b, wctx, info_);                    \
-        BT_SB();                                                                                   \
-        BODY(ch + 1, b);                                                                           \
-        BT_SB();                                                                                   \
-      }                                                                                            \
-    }                                                                                              \
-  }
-#define BT_NO_PRE(ch)
-#define BT_BODY_AH(ch, b)                                                                                          \
-  _Pragma("unroll") for (int i = 0; i < HCH; ++i) {                                                                \
-    acc_a = __builtin_amdgcn_mfma_f32_16x16x4f32(wa_h[2 * HCH * (ch) + i], b[i], acc_a, 0, 0, 0);                  \
-    acc_a3 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa_h[2 * HCH * (ch) + HCH + i], b[HCH + i], acc_a3, 0, 0, 0);    \
+    if (r0 < P) keep_l2 = *reinterpret_cast<const unsigned*>(a.masks + P + r0);     // frame 0, layer 2
   }
 
 #ifdef TACO_BT_STAMPS
   const int stamp_wg = j == 0 ? 0 : j == n_p_wg ? 1 : j == q_off ? 2 : j == a.n_wg - 1 ? 3 : -1;
 #endif
   for (;; ++t) {
-    const unsigned ep = (unsigned)t + 1u;
-    const unsigned par = (unsigned)(t & 1) * (unsigned)a.lay.per_parity;
-    taco_granule* g = a.gran + par;
+    const unsigned ep = (unsigned)t + 1u;                                  // epoch of the 8-byte granules
+    const unsigned tag = (((unsigned)t >> 1) & 1u) + 1u;                   // generation of this frame's words
+    const unsigned par = (unsigned)(t & 1) * (unsigned)a.lay.per_parity;   // word offset of this frame's parity block
+    uint32_t* gw = a.words + par;
+    taco_granule* g_pe = reinterpret_cast<taco_granule*>(gw + a.lay.pe);
     const int lane_f = BT_OPQ(lane);            // see BT_OPQ: addresses derived from these are recomputed every frame
     const int tid_f = lane_f + 64 * wave;
     const int utt_f = lane_f & 15, kq_f = lane_f >> 4;
@@ -599,51 +533,43 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
         kn2 = *reinterpret_cast<const unsigned*>(src + P);
       }
       if (t > 0) {
-        float b[2 * NPW_P];
+        u32x4 v[NL_P];
+        const float* w2 = lds + BT_OPQ(LP_W2 + wave * (4 * NL_P) * 64 + lane_f);
         bt_nap_begin(nap_h1, wctx);
-        bt_load_pairs<NPW_P>(rs, par + a.lay.h1 + g_lane_p, ep, b, wctx, 0x300u);
-        nap_h1 = taco_nap_adjust(nap_h1, wctx.spun);
-        f32x4 acc2 = {0.0f, 0.0f, 0.0f, 0.0f};
-        const float* w2 = lds + BT_OPQ(LP_W2 + wave * (2 * NPW_P) * 64 + lane_f);
+        bt_issue<NL_P>(rs, par + w_lane_h1, v);
+        float aop[4 * NL_P];
 #pragma unroll
-        for (int i = 0; i < NPW_P; ++i) {
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[i * 64], b[i], acc, 0, 0, 0);
-          acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[(NPW_P + i) * 64], b[NPW_P + i], acc2, 0, 0, 0);
-        }
+        for (int i = 0; i < 4 * NL_P; ++i) aop[i] = w2[i * 64];
+        bt_check<NL_P, 0, NL_P>(rs, par + w_lane_h1, tag, v, wctx, 0x300u);
+        nap_h1 = taco_nap_adjust(nap_h1, wctx.spun);
+        BT_SB();
+        f32x4 acc2 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int i = 0; i < NL_P; ++i) { BT_MFMA4(aop, i, v[i], acc, acc2) }
         acc += acc2;
       }
       acc = bt_reduce_tiles(lds, LP_RED, acc, wave, lane_f);
       if (wave == 0) {
+        float pv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = j * RP + 4 * kq + r;
           float v = acc[r] > 0.0f ? acc[r] : 0.0f;
           v = ((keep_l2 >> (8 * r)) & 0xffu) ? v * 2.0f : 0.0f;
-          bt_publish<REP>(g + a.lay.p, a.lay.p_cap, utt * KP + row, ep, row < P ? v : 0.0f);
+          pv[r] = row < P ? v : 0.0f;
         }
+        bt_store4<REP>(rs, par + (unsigned)(a.lay.p + utt * KP + j * RP + 4 * kq), a.lay.p_cap, tag, pv[0], pv[1], pv[2], pv[3]);
         keep_l1 = kn1;
         keep_next = kn2;
       }
       taco_lds_barrier();      // LP_RED is reused by the layer-1 rows below
-      if (t > 0) {
-        // while the prenet output travels: the hidden columns of this frame's attention-LSTM rows, on the previous frame's
-        // attention hidden state (the other workgroups did this at the end of that frame; here it would have sat between
-        // the layer-1 rows and layer 2, which everybody waits for)
-        const unsigned ep_prev = ep - 1u;
-        const unsigned par_prev = (unsigned)((t - 1) & 1) * (unsigned)a.lay.per_parity;
-        f32x4 acc_a3 = {0.0f, 0.0f, 0.0f, 0.0f};
-        {
-          const unsigned ep = ep_prev;
-          BT_STREAM_H(par_prev + a.lay.ah + g_lane_h, 0x680u, (void)0, BT_NO_PRE, BT_BODY_AH)
-        }
-        acc_a += acc_a3;
-      }
     }
 
     BT_STAMP(0);
     // ============ frame boundary: the previous frame's stop tokens ============
     if (t > 0) {
-      if (wave == 0 && lane < NB) lds[L_STOP + lane] = taco_wait_one(a.gran + (((t - 1) & 1) ? a.lay.per_parity : 0) + a.lay.stop + rep * a.lay.stop_cap, lane, (unsigned)t, wctx, 0x100u);
+      const taco_granule* g_stop = reinterpret_cast<const taco_granule*>(a.words + (((t - 1) & 1) ? a.lay.per_parity : 0) + a.lay.stop + rep * a.lay.stop_cap);
+      if (wave == 0 && lane < NB) lds[L_STOP + lane] = taco_wait_one(g_stop, lane, (unsigned)t, wctx, 0x100u);
       if (wctx.failed) lds[L_STOP + 16] = 1.0f;
       taco_lds_barrier();
       if (lds[L_STOP + 16] != 0.0f) break;
@@ -658,16 +584,20 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
 
     // ============ attention LSTM ============
     {
-      float b[2 * NPW_P];
+      u32x4 v[NL_P];
+      float4 wp4[NL_P];
+#pragma unroll
+      for (int i = 0; i < NL_P; ++i) wp4[i] = ws_lane[i * 64];         // my rows' prenet columns (L2), beside the wait below
       bt_nap_begin(nap_p, wctx);
-      bt_load_pairs<NPW_P>(rs, par + a.lay.p + g_lane_p, ep, b, wctx, 0x400u);
+      bt_issue<NL_P>(rs, par + w_lane_p, v);
+      bt_check<NL_P, 0, NL_P>(rs, par + w_lane_p, tag, v, wctx, 0x400u);
       nap_p = taco_nap_adjust(nap_p, wctx.spun);
       BT_STAMP(2);
       f32x4 acc2 = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-      for (int i = 0; i < NPW_P; ++i) {
-        acc_a = __builtin_amdgcn_mfma_f32_16x16x4f32(wa_p[i], b[i], acc_a, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa_p[NPW_P + i], b[NPW_P + i], acc2, 0, 0, 0);
+      for (int i = 0; i < NL_P; ++i) {
+        const float wp[4] = {wp4[i].x, wp4[i].y, wp4[i].z, wp4[i].w};
+        BT_MFMA4(wp, 0, v[i], acc_a, acc2)
       }
       acc_a += acc2;
       const f32x4 pre = bt_reduce_tiles(lds, L_RED, acc_a, wave, lane_f);
@@ -675,7 +605,7 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
         const f32x4 bias = *reinterpret_cast<const f32x4*>(lds + L_BIAS + 4 * kq_f);
         const float hv = bt_lstm_cell(pre, bias, c_a);
         const int hu = j * 4 + kq;
-        bt_publish<REP>(g + a.lay.ah, a.lay.ah_cap, utt * KH + hu, ep, hu < Ra ? hv : 0.0f);
+        bt_publish_units<REP>(rs, par + (unsigned)(a.lay.ah + utt * KH + j * 4), a.lay.ah_cap, tag, hu < Ra ? hv : 0.0f, lane);
       }
     }
     BT_STAMP(3);
@@ -683,12 +613,15 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
     // ============ Q: query values and partial energies of my 16 dimensions, every position of my utterance ============
     if (is_q) {
       {
-        const unsigned src[2] = {par + a.lay.ah + rep * a.lay.ah_cap + q_slot * KH + 2 * tid, par + a.lay.ah + rep * a.lay.ah_cap + q_slot * KH + 2 * (tid + NT)};
-        const int d0 = BT_OPQ(LQ_XPE + 2 * tid_f);
-        const int dst[2] = {d0, d0 + 2 * NT};
+        // the hidden state of my utterance: 1024 words, 16 bytes per thread
+        u32x4 v[1];
+        const unsigned src = par + (unsigned)(a.lay.ah + rep * a.lay.ah_cap + q_slot * KH) + 4u * (unsigned)tid_f;
         bt_nap_begin(nap_ahq, wctx);
-        bt_gather_pairs<2>(rs, src, dst, 2, ep, lds, wctx, 0x500u);
+        v[0] = __builtin_amdgcn_raw_buffer_load_b128(rs, src * 4u, 0, 16);
+        // (the loop of bt_check fetches from widx + 16 i: with one load that is the same address)
+        bt_check<1, 0, 1>(rs, src, tag, v, wctx, 0x500u);
         nap_ahq = taco_nap_adjust(nap_ahq, wctx.spun);
+        *reinterpret_cast<float4*>(lds + BT_OPQ(LQ_XPE + 4 * tid_f)) = make_float4(BT_F(v[0].x), BT_F(v[0].y), BT_F(v[0].z), BT_F(v[0].w));
       }
       taco_lds_barrier();
       BT_STAMP(4);
@@ -728,39 +661,74 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
             for (int r = 0; r < 4; ++r) e = fmaf(vq[r], taco_tanh(q4[r] + u4[r]), e);
             e += __shfl_xor(e, 16, 64);
             e += __shfl_xor(e, 32, 64);
-            if (kq_f == 0) taco_publish(g + a.lay.pe + (q_slot * NQ + dg) * TIN, s, ep, s < len ? e : 0.0f);
+            if (kq_f == 0) taco_publish(g_pe + (q_slot * NQ + dg) * TIN, s, ep, s < len ? e : 0.0f);
           }
         }
       }
     }
     BT_STAMP(5);
 
-    // ============ all: the attention hidden state into this frame's decoder-LSTM rows ============
+    // ============ all: the attention hidden state: its decoder-LSTM columns (this frame) and its attention-LSTM columns
+    //              (next frame) on the same operands ============
     f32x4 acc_d = acc_dn;
+    f32x4 acc_an = {0.0f, 0.0f, 0.0f, 0.0f};
     {
-      f32x4 acc_d2 = {0.0f, 0.0f, 0.0f, 0.0f};
+      u32x4 vah[NL_H];
+      f32x4 acc_d2 = {0.0f, 0.0f, 0.0f, 0.0f}, acc_an2 = {0.0f, 0.0f, 0.0f, 0.0f};
       bt_nap_begin(nap_ah, wctx);
-#define BT_BODY_DA(ch, b)                                                                                          \
-  _Pragma("unroll") for (int i = 0; i < HCH; ++i) {                                                                \
-    acc_d = __builtin_amdgcn_mfma_f32_16x16x4f32(wd_a[2 * HCH * (ch) + i], b[i], acc_d, 0, 0, 0);                  \
-    acc_d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wd_a[2 * HCH * (ch) + HCH + i], b[HCH + i], acc_d2, 0, 0, 0);    \
-  }
-      BT_STREAM_H(par + a.lay.ah + g_lane_h, 0x600u, nap_ah = taco_nap_adjust(nap_ah, wctx.spun), BT_NO_PRE, BT_BODY_DA)
-#undef BT_BODY_DA
+      bt_issue<NL_H>(rs, par + w_lane_ah, vah);
+      BT_SB();
+#define BT_AH_BURST(c)                                                                             \
+  bt_check<NL_H, BURST * (c), BURST>(rs, par + w_lane_ah, tag, vah, wctx, 0x600u);                  \
+  if ((c) == 0) nap_ah = taco_nap_adjust(nap_ah, wctx.spun);                                       \
+  BT_SB();                                                                                         \
+  _Pragma("unroll") for (int i = BURST * (c); i < BURST * (c) + BURST; ++i) {                      \
+    BT_MFMA4(wd_a, i, vah[i], acc_d, acc_d2)                                                       \
+    BT_MFMA4(wa_h, i, vah[i], acc_an, acc_an2)                                                     \
+  }                                                                                                \
+  BT_SB();
+      BT_AH_BURST(0) BT_AH_BURST(1) BT_AH_BURST(2) BT_AH_BURST(3)
+#undef BT_AH_BURST
       acc_d += acc_d2;
+      acc_an += acc_an2;
     }
     BT_STAMP(6);
 
     // ============ Q: energies of my utterance, softmax, my columns of the context ============
     if (is_q) {
-      bt_nap_begin(nap_pe, wctx);
       {
-        const unsigned src[4] = {par + pe_src0, par + pe_src0 + 64u, par + pe_src0 + 128u, par + pe_src0 + 192u};
+        // partial energies: 8-byte granules, two per 16-byte load
+        u32x4 v[4];
+        const unsigned src = par + pe_src0;
         const int pd = BT_OPQ(LQ_XPE + (tid_f >> 5) * TIN + 2 * (tid_f & 31));
-        const int dst[4] = {pd, pd + 64, pd + 128, pd + 192};
-        bt_gather_pairs<4>(rs, src, dst, pe_n, ep, lds, wctx, 0x700u);
+        unsigned spins = 0;
+        bt_nap_begin(nap_pe, wctx);
+        for (;;) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (src + 128u * i) * 4u, 0, 16);
+          unsigned bad = 0;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (i < pe_n) bad |= (v[i].y ^ ep) | (v[i].w ^ ep);
+          if (__all(bad == 0u) || wctx.failed) break;
+          wctx.spun = 1;
+          __builtin_amdgcn_s_sleep(TACO_POLL_SLEEP);
+          if ((++spins & 255u) == 0u) {
+            if (__hip_atomic_load(wctx.abort_word, TACO_RLX_AGENT) != 0u) { wctx.failed = 1; break; }
+            if (spins >= TACO_SPIN_LIMIT) {
+              __hip_atomic_store(wctx.abort_word, TACO_ABORT_TIMEOUT, TACO_RLX_AGENT);
+              __hip_atomic_store(wctx.abort_word + 1, 0x700u, TACO_RLX_AGENT);
+              wctx.failed = 1;
+              break;
+            }
+          }
+          asm volatile("" ::: "memory");
+        }
+        nap_pe = taco_nap_adjust(nap_pe, wctx.spun);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (i < pe_n) *reinterpret_cast<float2*>(lds + pd + 64 * i) = make_float2(BT_F(v[i].x), BT_F(v[i].z));
       }
-      nap_pe = taco_nap_adjust(nap_pe, wctx.spun);
       taco_lds_barrier();
       BT_STAMP(7);
       float w_own = 0.0f;
@@ -824,166 +792,185 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
         }
       }
       taco_lds_barrier();
-      if (tid < cw) {
-        float s = 0.0f;
-        const float* cp = lds + BT_OPQ(LQ_XPE + tid_f);
+      if (tid < CQ) {
+        // thread = column quad: the 15 groups' partial sums of its 4 columns, one 16-byte store (columns at or beyond M are zeros)
+        float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const float* cp = lds + BT_OPQ(LQ_XPE + 4 * tid_f);
 #pragma unroll
-        for (int pg = 0; pg < CPG; ++pg) s += cp[pg * MEMW];
-        bt_publish<REP>(g + a.lay.ctx, a.lay.ctx_cap, q_slot * KC + c0 + tid, ep, tid < c_cnt ? s : 0.0f);
-      } else if (dg == 0) {
+        for (int pg = 0; pg < CPG; ++pg) {
+          const float4 v = *reinterpret_cast<const float4*>(cp + pg * MEMW);
+          s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        bt_store4<REP>(rs, par + (unsigned)(a.lay.ctx + q_slot * KC + c0 + 4 * tid), a.lay.ctx_cap, tag, s.x, s.y, s.z, s.w);
+      } else if (dg == 0 && tid < CQ + (KC - NQ * MEMW) / 4) {
         // the padding columns of the exchanged vector
-        for (int c = NQ * cw + (tid - cw); c < KC; c += NT - cw) bt_publish<REP>(g + a.lay.ctx, a.lay.ctx_cap, q_slot * KC + c, ep, 0.0f);
+        bt_store4<REP>(rs, par + (unsigned)(a.lay.ctx + q_slot * KC + NQ * MEMW + 4 * (tid - CQ)), a.lay.ctx_cap, tag, 0.0f, 0.0f, 0.0f, 0.0f);
       }
       BT_STAMP(8);
-      // next frame's location term, while the context travels
-      update_location_term(lane_f);
-      BT_STAMP(9);
     }
     if (a.frame_clock && j == a.n_wg - 1 && tid == 0 && t < a.frame_clock_cap) a.frame_clock[t] = wall_clock64();
 
     // ============ all: the context finishes the decoder LSTM ============
     f32x4 acc_r = {0.0f, 0.0f, 0.0f, 0.0f};     // P: folded layer-1 rows; M: projection rows
+    f32x4 acc_r2 = {0.0f, 0.0f, 0.0f, 0.0f};
     {
-      constexpr int CCH = NPW_C / 2;          // two bursts of 9 pairs
-      bt_nap_begin(nap_ctx, wctx);
-      f32x4 acc_d2 = {0.0f, 0.0f, 0.0f, 0.0f};
-      u32x4 va[CCH], vb[CCH];
-      float b0[2 * CCH], b1[2 * CCH];
-      bt_issue<CCH>(rs, par + a.lay.ctx + g_lane_c, va);
-      bt_issue<CCH>(rs, par + a.lay.ctx + g_lane_c + 8u * CCH, vb);
-      bt_finish<CCH>(rs, par + a.lay.ctx + g_lane_c, ep, va, b0, wctx, 0x800u);
-      nap_ctx = taco_nap_adjust(nap_ctx, wctx.spun);
-      bt_finish<CCH>(rs, par + a.lay.ctx + g_lane_c + 8u * CCH, ep, vb, b1, wctx, 0x800u);
-      BT_STAMP(10);
-      // the decoder LSTM's rows first (two chains), its cell update and publish, then everything else on these operands
+      u32x4 vc[NL_C];
+      float4 wc4[NL_C];
 #pragma unroll
-      for (int i = 0; i < 2 * CCH; ++i) {
-        acc_d = __builtin_amdgcn_mfma_f32_16x16x4f32(wd_c[i], b0[i], acc_d, 0, 0, 0);
-        acc_d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wd_c[2 * CCH + i], b1[i], acc_d2, 0, 0, 0);
-      }
+      for (int i = 0; i < NL_C; ++i) wc4[i] = ws_lane[(NL_P + i) * 64];   // my attention-LSTM rows' context columns (L2): used after the publish below
+      bt_nap_begin(nap_ctx, wctx);
+      bt_issue<NL_C>(rs, par + w_lane_c, vc);
+      BT_SB();
+      f32x4 acc_d2 = {0.0f, 0.0f, 0.0f, 0.0f};
+      bt_check<NL_C, 0, 3>(rs, par + w_lane_c, tag, vc, wctx, 0x800u);
+      nap_ctx = taco_nap_adjust(nap_ctx, wctx.spun);
+      BT_STAMP(10);
+      BT_SB();
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { BT_MFMA4(wd_c, i, vc[i], acc_d, acc_d2) }
+      BT_SB();
+      bt_check<NL_C, 3, 3>(rs, par + w_lane_c, tag, vc, wctx, 0x800u);
+      BT_SB();
+#pragma unroll
+      for (int i = 3; i < 6; ++i) { BT_MFMA4(wd_c, i, vc[i], acc_d, acc_d2) }
+      BT_SB();
+      bt_check<NL_C, 6, 3>(rs, par + w_lane_c, tag, vc, wctx, 0x800u);
+      BT_SB();
+#pragma unroll
+      for (int i = 6; i < 9; ++i) { BT_MFMA4(wd_c, i, vc[i], acc_d, acc_d2) }
       acc_d += acc_d2;
       const f32x4 pre = bt_reduce_tiles(lds, L_RED, acc_d, wave, lane_f);
       if (wave == 0) {
         const f32x4 bias = *reinterpret_cast<const f32x4*>(lds + L_BIAS + 16 + 4 * kq_f);
         const float hv = bt_lstm_cell(pre, bias, c_d);
         const int hu = j * 4 + kq;
-        bt_publish<REP>(g + a.lay.dh, a.lay.dh_cap, utt * KH + hu, ep, hu < Rd ? hv : 0.0f);
+        bt_publish_units<REP>(rs, par + (unsigned)(a.lay.dh + utt * KH + j * 4), a.lay.dh_cap, tag, hu < Rd ? hv : 0.0f, lane);
       }
       BT_STAMP(11);
-      // while the decoder hidden state travels: the context columns of the P / M rows and of next frame's attention LSTM
+      BT_SB();
+      // while the decoder hidden state travels: the context columns of the P / M rows ...
       if ((is_p && !forced) || is_m) {
-        const float* crow = lds + BT_OPQ((is_p ? LP_WF : LM_W) + (KH / 4 + wave * 2 * NPW_C) * 64 + lane_f);
-        acc_r = bt_mfma_lds<2 * CCH>(crow, 0, b0, acc_r);
-        acc_r = bt_mfma_lds<2 * CCH>(crow + 2 * CCH * 64, 0, b1, acc_r);
+        const float* crow = lds + BT_OPQ((is_p ? LP_WF : LM_W) + (KH / 4 + wave * 4 * NL_C) * 64 + lane_f);
+#pragma unroll
+        for (int i = 0; i < NL_C; ++i) {
+          float aop[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) aop[e] = crow[(4 * i + e) * 64];
+          BT_MFMA4(aop, 0, vc[i], acc_r, acc_r2)
+        }
       }
-      acc_a = {0.0f, 0.0f, 0.0f, 0.0f};
+      // ... and the context columns of next frame's attention LSTM
+      acc_a = acc_an;
       f32x4 acc_a2 = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-      for (int i = 0; i < 2 * CCH; ++i) {
-        acc_a = __builtin_amdgcn_mfma_f32_16x16x4f32(wa_c[i], b0[i], acc_a, 0, 0, 0);
-        acc_a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa_c[2 * CCH + i], b1[i], acc_a2, 0, 0, 0);
+      for (int i = 0; i < NL_C; ++i) {
+        const float wc[4] = {wc4[i].x, wc4[i].y, wc4[i].z, wc4[i].w};
+        BT_MFMA4(wc, 0, vc[i], acc_a, acc_a2)
       }
       acc_a += acc_a2;
     }
-    // ... and its hidden columns, on a second fetch of this frame's attention hidden state (P / M do this after their rows)
-    if (!(is_p || is_m)) {
-      f32x4 acc_a3 = {0.0f, 0.0f, 0.0f, 0.0f};
-      BT_STREAM_H(par + a.lay.ah + g_lane_h, 0x680u, (void)0, BT_NO_PRE, BT_BODY_AH)
-      acc_a += acc_a3;
-    }
 
     // ============ the decoder hidden state; P: next frame's layer-1 rows; M: the frame's output ============
-    bt_nap_begin(nap_dh, wctx);
-    if (is_p || is_m) {
-      // these rows are what other workgroups wait for: they come first; the operands are fetched a second time
-      // for the recurrent products below
-      const float* rows = lds + BT_OPQ((is_p ? LP_WF : LM_W) + (wave * 2 * NPW_H) * 64 + lane_f);
-      const bool use_rows = is_m || !forced;
-      f32x4 acc_r2 = {0.0f, 0.0f, 0.0f, 0.0f};
-      float aop[2 * HCH];
-#define BT_PRE_ROWS(ch)                                                                                            \
-  if (use_rows) {                                                                                                  \
-    _Pragma("unroll") for (int i = 0; i < 2 * HCH; ++i) aop[i] = rows[(2 * HCH * (ch) + i) * 64];                  \
+    {
+      u32x4 vdh[NL_H];
+      bt_nap_begin(nap_dh, wctx);
+      bt_issue<NL_H>(rs, par + w_lane_dh, vdh);
+      BT_SB();
+      if (is_p || is_m) {
+        // these rows are what other workgroups wait for: they come first, on operands that stay in registers for the
+        // recurrent products afterwards
+        const float* rows = lds + BT_OPQ((is_p ? LP_WF : LM_W) + (wave * 4 * NL_H) * 64 + lane_f);
+        const bool use_rows = is_m || !forced;
+#define BT_ROWS_BURST(c)                                                                           \
+  {                                                                                                \
+    float aop[4 * BURST];                                                                          \
+    if (use_rows) {                                                                                \
+      _Pragma("unroll") for (int i = 0; i < 4 * BURST; ++i) aop[i] = rows[(4 * BURST * (c) + i) * 64]; \
+    }                                                                                              \
+    bt_check<NL_H, BURST * (c), BURST>(rs, par + w_lane_dh, tag, vdh, wctx, 0x900u);                \
+    if ((c) == 0) { nap_dh = taco_nap_adjust(nap_dh, wctx.spun); BT_STAMP(12); }                   \
+    BT_SB();                                                                                       \
+    if (use_rows) {                                                                                \
+      _Pragma("unroll") for (int i = 0; i < BURST; ++i) { BT_MFMA4(aop, i, vdh[BURST * (c) + i], acc_r, acc_r2) } \
+    }                                                                                              \
+    BT_SB();                                                                                       \
   }
-#define BT_BODY_ROWS(ch, b)                                                                                        \
-  if (use_rows) {                                                                                                  \
-    _Pragma("unroll") for (int i = 0; i < HCH; ++i) {                                                              \
-      acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[i], b[i], acc_r, 0, 0, 0);                                  \
-      acc_r2 = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[HCH + i], b[HCH + i], acc_r2, 0, 0, 0);                    \
-    }                                                                                                              \
-  }
-      BT_STREAM_H(par + a.lay.dh + g_lane_h, 0x900u, nap_dh = taco_nap_adjust(nap_dh, wctx.spun); BT_STAMP(12), BT_PRE_ROWS, BT_BODY_ROWS)
-#undef BT_PRE_ROWS
-#undef BT_BODY_ROWS
-      acc_r += acc_r2;
-      if (is_p && forced && t + 1 < a.max_steps) {
-        // teacher forcing: the plain layer-1 rows on the given frame (wave w takes k-steps 5w .. 5w + 4)
-        constexpr int W1_PER_WAVE = (W1_KSTEPS + NW - 1) / NW;
-        const float* w1row = lds + BT_OPQ(LP_W1 + W1_PER_WAVE * wave * 64 + lane_f);
+        BT_ROWS_BURST(0) BT_ROWS_BURST(1) BT_ROWS_BURST(2) BT_ROWS_BURST(3)
+#undef BT_ROWS_BURST
+        acc_r += acc_r2;
+        if (is_p && forced && t + 1 < a.max_steps) {
+          // teacher forcing: the plain layer-1 rows on the given frame (wave w takes k-steps 5w .. 5w + 4)
+          constexpr int W1_PER_WAVE = (W1_KSTEPS + NW - 1) / NW;
+          const float* w1row = lds + BT_OPQ(LP_W1 + W1_PER_WAVE * wave * 64 + lane_f);
 #pragma unroll
-        for (int i = 0; i < W1_PER_WAVE; ++i) {
-          const int ks = W1_PER_WAVE * wave + i;
-          const int k = 8 * (ks >> 1) + 2 * kq_f + (ks & 1);
-          float xv = 0.0f;
-          if (ks < W1_KSTEPS && k < NMEL) xv = a.forced_mel[((size_t)reinterpret_cast<const int*>(lds + L_UTT)[utt_f] * NMEL + k) * a.T_cap + t];
-          if (ks < W1_KSTEPS) acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(w1row[i * 64], xv, acc_r, 0, 0, 0);
+          for (int i = 0; i < W1_PER_WAVE; ++i) {
+            const int ks = W1_PER_WAVE * wave + i;
+            const int k = 16 * (ks >> 2) + 4 * kq_f + (ks & 3);
+            float xv = 0.0f;
+            if (ks < W1_KSTEPS && k < NMEL) xv = a.forced_mel[((size_t)reinterpret_cast<const int*>(lds + L_UTT)[utt_f] * NMEL + k) * a.T_cap + t];
+            if (ks < W1_KSTEPS) acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(w1row[i * 64], xv, acc_r, 0, 0, 0);
+          }
         }
-      }
-      const f32x4 sum = bt_reduce_tiles(lds, is_p ? LP_RED : LM_RED, acc_r, wave, lane_f);
-      if (wave == 0) {
-        if (is_p) {
-          if (t + 1 < a.max_steps) {
-            taco_granule* gn = a.gran + (((t + 1) & 1) ? a.lay.per_parity : 0);
+        const f32x4 sum = bt_reduce_tiles(lds, is_p ? LP_RED : LM_RED, acc_r, wave, lane_f);
+        if (wave == 0) {
+          if (is_p) {
+            if (t + 1 < a.max_steps) {
+              const unsigned par_n = ((t + 1) & 1) ? (unsigned)a.lay.per_parity : 0u;
+              const unsigned tag_n = ((((unsigned)t + 1u) >> 1) & 1u) + 1u;
+              float hv1[4];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int row = j * RP + 4 * kq + r;
+                float v = sum[r] + (forced ? 0.0f : lds[LP_BIAS + 4 * kq + r]);
+                v = v > 0.0f ? v : 0.0f;
+                v = ((keep_l1 >> (8 * r)) & 0xffu) ? v * 2.0f : 0.0f;
+                hv1[r] = row < P ? v : 0.0f;
+              }
+              bt_store4<REP>(rs, par_n + (unsigned)(a.lay.h1 + utt * KP + j * RP + 4 * kq), a.lay.h1_cap, tag_n, hv1[0], hv1[1], hv1[2], hv1[3]);
+              keep_l2 = keep_next;
+            }
+          } else {
+            const int b_out = reinterpret_cast<const int*>(lds + L_UTT)[utt];
+            const bool wr = (alive >> utt) & 1u;
+            taco_granule* g_stop = reinterpret_cast<taco_granule*>(gw + a.lay.stop);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const int row = j * RP + 4 * kq + r;
-              float v = sum[r] + (forced ? 0.0f : lds[LP_BIAS + 4 * kq + r]);
-              v = v > 0.0f ? v : 0.0f;
-              v = ((keep_l1 >> (8 * r)) & 0xffu) ? v * 2.0f : 0.0f;
-              bt_publish<REP>(gn + a.lay.h1, a.lay.h1_cap, utt * KP + row, ep + 1u, row < P ? v : 0.0f);
-            }
-            keep_l2 = keep_next;
-          }
-        } else {
-          const int b_out = reinterpret_cast<const int*>(lds + L_UTT)[utt];
-          const bool wr = (alive >> utt) & 1u;
+              const int row = (j - n_p_wg) * RP + 4 * kq + r;
+              const float v = sum[r] + lds[LM_BIAS + 4 * kq + r];
+              if (row < NMEL) {
+                if (wr) a.mel[((size_t)b_out * NMEL + row) * a.T_cap + t] = v;
+              } else if (row == NMEL) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = (j - n_p_wg) * RP + 4 * kq + r;
-            const float v = sum[r] + lds[LM_BIAS + 4 * kq + r];
-            if (row < NMEL) {
-              if (wr) a.mel[((size_t)b_out * NMEL + row) * a.T_cap + t] = v;
-            } else if (row == NMEL) {
-              bt_publish<REP>(g + a.lay.stop, a.lay.stop_cap, utt, ep, v);
-              if (wr) a.gate[(size_t)b_out * a.T_cap + t] = v;
+                for (int rr = 0; rr < REP; ++rr) taco_publish(g_stop + (size_t)rr * (a.lay.stop_cap / 2), utt, ep, v);
+                if (wr) a.gate[(size_t)b_out * a.T_cap + t] = v;
+              }
             }
           }
         }
-      }
-      BT_STAMP(13);
-      if (is_m) {     // (P: at the top of the next frame, after it has published the prenet output)
-        f32x4 acc_a3 = {0.0f, 0.0f, 0.0f, 0.0f};
-        BT_STREAM_H(par + a.lay.ah + g_lane_h, 0x680u, (void)0, BT_NO_PRE, BT_BODY_AH)
-        acc_a += acc_a3;
+        BT_STAMP(13);
+        acc_dn = {0.0f, 0.0f, 0.0f, 0.0f};
+        f32x4 acc_dn2 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int i = 0; i < NL_H; ++i) { BT_MFMA4(wd_h, i, vdh[i], acc_dn, acc_dn2) }
+        acc_dn += acc_dn2;
+      } else {
+        acc_dn = {0.0f, 0.0f, 0.0f, 0.0f};
+        f32x4 acc_dn2 = {0.0f, 0.0f, 0.0f, 0.0f};
+#define BT_DH_BURST(c)                                                                             \
+  bt_check<NL_H, BURST * (c), BURST>(rs, par + w_lane_dh, tag, vdh, wctx, 0x980u);                  \
+  if ((c) == 0) { nap_dh = taco_nap_adjust(nap_dh, wctx.spun); BT_STAMP(12); }                     \
+  BT_SB();                                                                                         \
+  _Pragma("unroll") for (int i = BURST * (c); i < BURST * (c) + BURST; ++i) { BT_MFMA4(wd_h, i, vdh[i], acc_dn, acc_dn2) } \
+  BT_SB();
+        BT_DH_BURST(0) BT_DH_BURST(1) BT_DH_BURST(2) BT_DH_BURST(3)
+#undef BT_DH_BURST
+        acc_dn += acc_dn2;
       }
     }
-    {
-      const bool first_fetch = !(is_p || is_m);
-      acc_dn = {0.0f, 0.0f, 0.0f, 0.0f};
-      f32x4 acc_dn2 = {0.0f, 0.0f, 0.0f, 0.0f};
-#define BT_BODY_DH(ch, b)                                                                                          \
-  _Pragma("unroll") for (int i = 0; i < HCH; ++i) {                                                                \
-    acc_dn = __builtin_amdgcn_mfma_f32_16x16x4f32(wd_h[2 * HCH * (ch) + i], b[i], acc_dn, 0, 0, 0);                \
-    acc_dn2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wd_h[2 * HCH * (ch) + HCH + i], b[HCH + i], acc_dn2, 0, 0, 0);  \
-  }
-      BT_STREAM_H(par + a.lay.dh + g_lane_h, 0x980u, if (first_fetch) { nap_dh = taco_nap_adjust(nap_dh, wctx.spun); BT_STAMP(12); }, BT_NO_PRE, BT_BODY_DH)
-#undef BT_BODY_DH
-      acc_dn += acc_dn2;
-    }
+    // Q: next frame's location term, while the P group works on the next frame's prenet output
+    if (is_q) update_location_term(lane_f);
     BT_STAMP(14);
   }
-#undef BT_STREAM_H
-#undef BT_BODY_AH
 
   if (j == 0 && tid < a.n_utts) {
     const bool was_alive = (alive >> tid) & 1u;
@@ -999,33 +986,71 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
   }
 }
 
+// One-time re-packing of the attention LSTM's input columns (prenet output | context) into the order the frame loop
+// streams them in: out[((wg * 4 + wave) * 13 + load) * 64 + lane] = the four A operands (one float4) of lane `lane` for
+// the four k-steps of `load` (loads 0..3: prenet columns, 4..12: context columns); same row / column map as the
+// register-resident rows.
+__global__ void taco_bt_pack_kernel(const float* att_w_ih, int P, int M, int Ra, float4* out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  constexpr int NLD = NL_P + NL_C;
+  if (idx >= TACO_BT_WGS * NW * NLD * 64) return;
+  const int lane = idx & 63, li = (idx >> 6) % NLD, wave = ((idx >> 6) / NLD) % NW, wg = (idx >> 6) / (NLD * NW);
+  const int row16 = lane & 15, kq = lane >> 4;
+  const int hid = wg * 4 + (row16 >> 2), gate = row16 & 3;
+  float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (hid < Ra) {
+    const float* row = att_w_ih + ((size_t)gate * Ra + hid) * (P + M);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (li < NL_P) {
+        const int k = 16 * (wave * NL_P + li) + 4 * kq + e;
+        if (k < P) v[e] = row[k];
+      } else {
+        const int k = 16 * (wave * NL_C + (li - NL_P)) + 4 * kq + e;
+        if (k < M) v[e] = row[P + k];
+      }
+    }
+  }
+  out[idx] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
 }  // namespace
+
+size_t taco_decoder_batch_wstream_floats() { return (size_t)TACO_BT_WGS * NW * (NL_P + NL_C) * 64 * 4; }
+
+int taco_decoder_batch_pack(taco_handle h) {
+  const int n = TACO_BT_WGS * NW * (NL_P + NL_C) * 64;
+  hipLaunchKernelGGL(taco_bt_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, h->w.att_w_ih, h->d.P, h->d.M, h->d.R_a,
+                     reinterpret_cast<float4*>(h->bat_wstream));
+  TACO_HIP(hipGetLastError());
+  return TACO_OK;
+}
 
 size_t taco_decoder_batch_lds_bytes() { return (size_t)L_TOTAL * sizeof(float); }
 
 void taco_decoder_batch_fill_layout(taco_bat_layout* lay) {
   int off = 0;
-  auto take = [&](int n, int reps, int32_t& cap) {
+  auto take = [&](int n, int reps, int32_t* cap) {
     const int at = off;
-    cap = (n + 15) / 16 * 16;
-    off += cap * reps;
+    const int c = (n + 31) / 32 * 32;      // 128-byte aligned replicas
+    if (cap) *cap = c;
+    off += c * reps;
     return at;
   };
-  lay->h1 = take(NB * KP, TACO_BT_REP, lay->h1_cap);
-  lay->p = take(NB * KP, TACO_BT_REP, lay->p_cap);
-  lay->ah = take(NB * KH, TACO_BT_REP, lay->ah_cap);
-  int32_t pe_cap;
-  lay->pe = take(NB * NQ * TIN, 1, pe_cap);
-  lay->ctx = take(NB * KC, TACO_BT_REP, lay->ctx_cap);
-  lay->dh = take(NB * KH, TACO_BT_REP, lay->dh_cap);
-  lay->stop = take(NB, TACO_BT_REP, lay->stop_cap);
+  lay->h1 = take(NB * KP, TACO_BT_REP, &lay->h1_cap);
+  lay->p = take(NB * KP, TACO_BT_REP, &lay->p_cap);
+  lay->ah = take(NB * KH, TACO_BT_REP, &lay->ah_cap);
+  lay->ctx = take(NB * KC, TACO_BT_REP, &lay->ctx_cap);
+  lay->dh = take(NB * KH, TACO_BT_REP, &lay->dh_cap);
+  lay->pe = take(2 * NB * NQ * TIN, 1, nullptr);          // 8-byte granules: two words each
+  lay->stop = take(2 * NB, TACO_BT_REP, &lay->stop_cap);
   lay->per_parity = off;
 }
 
-size_t taco_decoder_batch_granules() {
+size_t taco_decoder_batch_handoff_bytes() {
   taco_bat_layout lay;
   taco_decoder_batch_fill_layout(&lay);
-  return (size_t)lay.per_parity * 2;
+  return (size_t)lay.per_parity * 2 * sizeof(uint32_t);
 }
 
 // Whether the lockstep kernel can run this model at all (extents within its capacities).
@@ -1060,9 +1085,9 @@ void taco_decoder_batch_dump_stamps(int n_frames) {
   const int nfr = n_frames < BT_STAMP_FRAMES ? n_frames : BT_STAMP_FRAMES;
   static const char* wgn[4] = {"P (0)", "M (first)", "Q (first)", "plain (last)"};
   static const char* names[BT_STAMP_POINTS] = {"top: P layer 2 + publish p", "stop test", "p loaded", "att MFMA+reduce+cell+publish ah",
-      "Q: ah gathered", "Q: query+energies+publish pe", "bulk ah loads + MFMAs", "Q: pe gathered", "Q: softmax+ctx+publish",
-      "Q: location term", "ctx loaded", "dec MFMA+reduce+cell+publish dh", "dh first half loaded", "P/M rows+epilogue (incl 2nd half load)",
-      "recurrent MFMAs", ""};
+      "Q: ah gathered", "Q: query+energies+publish pe", "ah loads + dec columns", "Q: pe gathered", "Q: softmax+ctx+publish",
+      "-", "ctx first burst loaded", "dec MFMA+reduce+cell+publish dh", "slack products + dh first burst", "P/M rows+epilogue",
+      "recurrent MFMAs (+ Q: location term)", ""};
   for (int wg = 0; wg < 4; ++wg) {
     double acc[BT_STAMP_POINTS] = {0};
     int cnt = 0;
@@ -1106,15 +1131,16 @@ int taco_launch_decoder_batch(taco_handle h, const float* memory, const float* p
   a.query_w = w.query_w; a.v_w = w.v_w; a.loc_fold = h->loc_fold;
   a.dec_w_ih = w.dec_w_ih; a.dec_w_hh = w.dec_w_hh; a.dec_b_ih = w.dec_b_ih; a.dec_b_hh = w.dec_b_hh;
   a.proj_w = w.proj_w; a.proj_b = w.proj_b; a.gate_w = w.gate_w; a.gate_b = w.gate_b;
+  a.wstream = reinterpret_cast<const float4*>(h->bat_wstream);
   a.memory = memory; a.pm = pm; a.masks = masks; a.T_cap = T_cap; a.max_steps = max_steps; a.thr = thr;
   a.shift_energies = h->energy_bound > 64.0f ? 1 : 0;
   a.forced_mel = forced_mel; a.mel = mel; a.gate = gate; a.align = align; a.n_frames = n_frames; a.reached = reached;
-  a.gran = h->bat_gran; a.lay = h->bat_lay;
-  a.gran_bytes = (unsigned)((size_t)h->bat_lay.per_parity * 2 * sizeof(taco_granule));
+  a.words = h->bat_gran; a.lay = h->bat_lay;
+  a.words_bytes = (unsigned)taco_decoder_batch_handoff_bytes();
   a.ctl = h->dec_ctl + group;
   a.frame_clock = group == 0 ? h->frame_clock : nullptr;
   a.frame_clock_cap = h->frame_clock_cap;
-  TACO_HIP(hipMemsetAsync(h->bat_gran, 0, a.gran_bytes, s));
+  TACO_HIP(hipMemsetAsync(h->bat_gran, 0, a.words_bytes, s));
 #ifdef TACO_BT_STAMPS
   {
     const size_t n = (size_t)4 * BT_STAMP_FRAMES * BT_STAMP_POINTS;

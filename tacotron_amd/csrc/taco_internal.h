@@ -71,10 +71,14 @@ constexpr int TACO_BT_ROWS = 16;        // rows per P / M workgroup
 #ifndef TACO_BT_REP
 #define TACO_BT_REP 2                   // replicas of every all-to-all vector
 #endif
-struct taco_bat_layout {                // granule offsets inside one parity block; vectors are [utterance][k]
-  int32_t h1, p, ah, pe, ctx, dh, stop;
-  int32_t h1_cap, p_cap, ah_cap, ctx_cap, dh_cap, stop_cap;   // replica strides
-  int32_t per_parity;
+struct taco_bat_layout {                // offsets in 4-byte words inside one parity block
+  // all-to-all vectors, [utterance][k] tagged fp32 words, TACO_BT_REP replicas each
+  int32_t h1, p, ah, ctx, dh;
+  int32_t h1_cap, p_cap, ah_cap, ctx_cap, dh_cap;             // replica strides (words)
+  // 8-byte {epoch, fp32} granules (even word offsets): partial energies [utterance][8 groups][positions], stop tokens [16]
+  int32_t pe, stop;
+  int32_t stop_cap;                                           // replica stride of the stop tokens (words)
+  int32_t per_parity;                                         // words per parity block
 };
 
 struct taco_dec_ctl {      // device-visible control block (zeroed before every launch)
@@ -122,8 +126,9 @@ struct taco_handle_s {
   int enc_group;             // utterances per launch of the encoder recurrence (0 = not worked out yet)
   taco_granule* dec_gran;    // decoder hand-off words, 2 parities
   taco_dec_layout dec_lay;
-  taco_granule* bat_gran;    // lockstep decoder hand-off words, 2 parities (NULL when the model exceeds its capacities)
+  uint32_t* bat_gran;        // lockstep decoder hand-off words, 2 parities (NULL when the model exceeds its capacities)
   taco_bat_layout bat_lay;
+  float* bat_wstream;        // attention-LSTM input columns in the lockstep kernel's streaming order
   int bat_ok;                // the lockstep kernel can run this model
   taco_dec_ctl* dec_ctl;     // device, one block per launch of a taco_decode call (grow-only)
   taco_dec_ctl* dec_ctl_host;  // pinned host mirror
@@ -170,10 +175,12 @@ int taco_launch_decoder_batch(taco_handle h, const float* memory, const float* p
                               const float* forced_mel, float* mel, float* gate, float* align, int32_t* n_frames,
                               uint8_t* reached, hipStream_t s);
 size_t taco_decoder_batch_lds_bytes();
-size_t taco_decoder_batch_granules();
+size_t taco_decoder_batch_handoff_bytes();
 void taco_decoder_batch_fill_layout(taco_bat_layout* lay);
 int taco_decoder_batch_supported(const taco_dims& d, int n_wg);
 int taco_decoder_batch_prepare(taco_handle h);
+size_t taco_decoder_batch_wstream_floats();
+int taco_decoder_batch_pack(taco_handle h);   // fills bat_wstream (after the weight pool is in place)
 size_t taco_decoder_lds_bytes();
 size_t taco_decoder_granules(int n_wg);
 void taco_decoder_fill_layout(taco_dec_layout* lay, int n_wg);

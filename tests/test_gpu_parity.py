@@ -308,42 +308,132 @@ def test_padded_batch_across_the_chunk_boundary(gate_table):
       assert not align[b, :, ln:].any() and not mem[b, ln:].any()
 
 
-def test_batch_of_64_equals_single_runs_at_full_size(gate_table):
+def _oracle_single(om, ids, b, ln, masks, max_steps, **kw):
+  """The oracle's run of utterance b of a padded id set, alone and unpadded: (mel, gate, align, n_frames, reached)."""
+  one = {k: (None if v is None else v[b:b + 1, :ln]) for k, v in ids.items() if k != "lens"}
+  mem_o, pm_o = om.encode(chans(one), one["speakers"], None)
+  mel_o, gate_o, align_o, nf_o, reached_o, _ = om.decode(mem_o, pm_o, None, masks.numpy(), max_steps, **kw)
+  return mem_o, mel_o[0], gate_o[0], align_o[0], int(nf_o[0]), int(reached_o[0])
+
+
+def test_batch_of_64_every_utterance_equals_its_own_oracle_run(gate_table, monkeypatch):
   """The batched configuration at the LJS-sized model's extents: 64 ragged lines (40..160 symbols) in one padded
-  batch, stop test live.  Size-independent property: every utterance of the batch equals the same line run alone
-  (encoder outputs, frames, gate values, alignments, frame count), and everything past an utterance's length and
-  frames is zero.  Tolerance 1e-5: the arithmetic per utterance is the same, only buffer strides differ."""
+  batch, stop test live, decoded sixteen to a launch by the lockstep kernel.  EVERY utterance must equal the CPU
+  checker's run of the same line alone: stop frame identical, frames / stop energies / alignments within the
+  free-running tolerance, everything past its length and its frames zero.  The same batch decoded one utterance per
+  launch (the batch-1 kernel) must agree too."""
   gate = gate_table["ljs"]
   gm = gpu_model("ljs", gate)
+  om = oracle_model("ljs", gate)
   ck = scenario_checkpoint("ljs", gate)
   r = np.random.RandomState(64)
   lens = [int(v) for v in r.randint(40, 161, size=64)]
   lens[0], lens[1] = 160, 40
   max_steps = 120
   ids = scenarios.random_ids(ck, lens, seed=6464)
+  for b in range(64):
+    ids["speakers"][b, :] = ids["speakers"][b, 0]
   masks = prenet_keep_masks(5, max_steps, gm.dims.P)
   lens_d = dev(np.array(lens, np.int32))
   mem, pm = gm.encode([dev(c) for c in chans(ids)], dev(ids["speakers"]), lens_d)
+  monkeypatch.setenv("TACO_DECODER", "lockstep")
   mel, gate_g, align, nf, reached = gm.decode(mem, pm, lens_d, masks, max_steps)
   post = gm.postnet(mel, nf)
-  nf_l = nf.cpu().tolist()
-  assert all(1 <= n <= max_steps for n in nf_l)
-  for b in (0, 1, 2, 17, 40, 63):
-    ln = lens[b]
-    one = {k: (None if v is None else v[b:b + 1, :ln]) for k, v in ids.items() if k != "lens"}
-    mem1, pm1 = gm.encode([dev(c) for c in chans(one)], dev(one["speakers"]), None)
-    mel1, gate1, align1, nf1, reached1 = gm.decode(mem1, pm1, None, masks, max_steps)
-    post1 = gm.postnet(mel1, nf1)
-    n = int(nf1[0])
-    assert nf_l[b] == n and bool(reached[b]) == bool(reached1[0])
-    tol = dict(atol=1e-5, rtol=0)
-    np.testing.assert_allclose(mem[b, :ln].cpu().numpy(), mem1[0].cpu().numpy(), **tol)
-    np.testing.assert_allclose(mel[b, :, :n].cpu().numpy(), mel1[0, :, :n].cpu().numpy(), **tol)
-    np.testing.assert_allclose(post[b, :, :n].cpu().numpy(), post1[0, :, :n].cpu().numpy(), **tol)
-    np.testing.assert_allclose(gate_g[b, :n].cpu().numpy(), gate1[0, :n].cpu().numpy(), **tol)
-    np.testing.assert_allclose(align[b, :n, :ln].cpu().numpy(), align1[0, :n, :ln].cpu().numpy(), **tol)
-    assert not mem[b, ln:].any() and not align[b, :, ln:].any()
-    assert not mel[b, :, n:].any() and not post[b, :, n:].any()
+  monkeypatch.setenv("TACO_DECODER", "single")
+  mel_s, gate_s, align_s, nf_s, reached_s = gm.decode(mem, pm, lens_d, masks, max_steps)
+  monkeypatch.delenv("TACO_DECODER")
+  assert nf.cpu().tolist() == nf_s.cpu().tolist() and reached.cpu().tolist() == reached_s.cpu().tolist()
+  stops = set()
+  for b, ln in enumerate(lens):
+    mem_o, mel_o, gate_o, align_o, n, reached_o = _oracle_single(om, ids, b, ln, masks, max_steps)
+    assert int(nf[b]) == n and int(reached[b]) == reached_o, (b, int(nf[b]), n)
+    stops.add(n)
+    tol = dict(atol=FREE_TOL, rtol=0)
+    np.testing.assert_allclose(mem[b, :ln].cpu().numpy(), mem_o[0], atol=TF_TOL, rtol=0)
+    np.testing.assert_allclose(mel[b, :, :n].cpu().numpy(), mel_o[:, :n], **tol)
+    np.testing.assert_allclose(gate_g[b, :n].cpu().numpy(), gate_o[:n], **tol)
+    np.testing.assert_allclose(align[b, :n, :ln].cpu().numpy(), align_o[:n], **tol)
+    np.testing.assert_allclose(mel_s[b, :, :n].cpu().numpy(), mel_o[:, :n], **tol)
+    assert not mem[b, ln:].any() and not align[b, :, ln:].any() and not align[b, n:].any()
+    assert not mel[b, :, n:].any() and not post[b, :, n:].any() and not gate_g[b, n:].any()
+  assert len(stops) > 4, "the stop frames of the batch should differ (one stop flag per utterance)"
+  assert bool(torch.isfinite(post).all())
+
+
+@pytest.mark.parametrize("name", ["tiny", "ljs", "thchs"])
+def test_lockstep_teacher_forced_matches_reference(name, monkeypatch):
+  """The lockstep kernel under teacher forcing against the reference's own frames (tolerance 1e-4, as for the batch-1
+  kernel): a group holding the golden utterance three times among utterances of other lengths - every copy must
+  reproduce the reference frame by frame - and a group of one (fifteen empty slots)."""
+  z, meta = load_golden(name)
+  om = oracle_model(meta["scenario"], meta["gate"])
+  gm = gpu_model(meta["scenario"], meta["gate"])
+  ck = scenario_checkpoint(meta["scenario"], meta["gate"])
+  ids1 = golden_ids(z)
+  n = meta["n_frames"]
+  T1 = ids1["symbols"].shape[1]
+  other_lens = [7, min(T1 + 31, 208), 64]
+  lens = [T1, other_lens[0], T1, other_lens[1], other_lens[2], T1]
+  ids = scenarios.random_ids(ck, lens, seed=31)
+  for b, ln in enumerate(lens):
+    if ln == T1 and b in (0, 2, 5):
+      for k in ("symbols", "stresses", "tones", "durations", "speakers"):
+        if ids[k] is not None:
+          ids[k][b, :T1] = ids1[k][0]
+    ids["speakers"][b, :] = ids["speakers"][b, 0]
+  masks = prenet_keep_masks(meta["seed"], n, om.dims.P)
+  lens_d = dev(np.array(lens, np.int32))
+  mem, pm = gm.encode([dev(c) for c in chans(ids)], dev(ids["speakers"]), lens_d)
+  forced = torch.zeros(len(lens), om.dims.n_mel, n, device="cuda:0")
+  refs = {}
+  for b, ln in enumerate(lens):
+    if b in (0, 2, 5):
+      forced[b] = dev(z["mel"])
+    else:    # the other utterances are forced with the checker's own free-running frames
+      refs[b] = _oracle_single(om, ids, b, ln, masks, n, gate_threshold=2.0)
+      forced[b] = dev(refs[b][1])
+  monkeypatch.setenv("TACO_DECODER", "lockstep")
+  mel, gate, align, nf, reached = gm.decode(mem, pm, lens_d, masks, n, forced_mel=forced)
+  assert nf.cpu().tolist() == [n] * len(lens) and not reached.any()
+  for b in (0, 2, 5):
+    np.testing.assert_allclose(mel[b].cpu().numpy(), z["mel"], atol=TF_TOL, rtol=0)
+    np.testing.assert_allclose(gate[b].cpu().numpy(), z["gate"], atol=TF_TOL, rtol=0)
+    np.testing.assert_allclose(align[b, :, :T1].cpu().numpy(), z["alignments"], atol=TF_TOL, rtol=0)
+  for b, ref in refs.items():     # (checker against kernel over up to 171 frames of random-weight recurrences: the looser tolerance)
+    np.testing.assert_allclose(mel[b].cpu().numpy(), ref[1], atol=FREE_TOL, rtol=0)
+    np.testing.assert_allclose(align[b, :, :lens[b]].cpu().numpy(), ref[3], atol=FREE_TOL, rtol=0)
+  # a group of one
+  mem1, pm1 = gm.encode([dev(c) for c in chans(ids1)], dev(ids1["speakers"]), None)
+  mel1, gate1, align1, nf1, _ = gm.decode(mem1, pm1, None, masks, n, forced_mel=dev(z["mel"][None]))
+  assert int(nf1[0]) == n
+  np.testing.assert_allclose(mel1[0].cpu().numpy(), z["mel"], atol=TF_TOL, rtol=0)
+  np.testing.assert_allclose(align1[0].cpu().numpy(), z["alignments"], atol=TF_TOL, rtol=0)
+
+
+def test_lockstep_groups_and_long_lines_mix(gate_table):
+  """Seventeen-plus utterances (a full group and a part-filled one) with lines on both sides of the lockstep kernel's
+  208-symbol capacity (the long ones run the batch-1 kernel inside the same call), one-symbol lines, a stop on the
+  first frames: every utterance against the checker."""
+  for name, lens, max_steps in (("tiny", [208, 209, 1, 300, 16, 2, 207, 64, 33, 512, 5, 100, 3, 256, 9, 77, 150, 12, 200, 41], 14),
+                                ("ljs", [209, 208, 30, 3], 6)):
+    gate = gate_table[name]
+    om = oracle_model(name, gate)
+    gm = gpu_model(name, gate)
+    ck = scenario_checkpoint(name, gate)
+    ids = scenarios.random_ids(ck, lens, seed=2323)
+    for b in range(len(lens)):
+      ids["speakers"][b, :] = ids["speakers"][b, 0]
+    masks = prenet_keep_masks(13, max_steps, om.dims.P)
+    lens_d = dev(np.array(lens, np.int32))
+    mem, pm = gm.encode([dev(c) for c in chans(ids)], dev(ids["speakers"]), lens_d)
+    mel, gate_g, align, nf, reached = gm.decode(mem, pm, lens_d, masks, max_steps)
+    for b, ln in enumerate(lens):
+      _, mel_o, gate_o, align_o, n, reached_o = _oracle_single(om, ids, b, ln, masks, max_steps)
+      assert int(nf[b]) == n and int(reached[b]) == reached_o, (name, b, ln)
+      np.testing.assert_allclose(mel[b, :, :n].cpu().numpy(), mel_o[:, :n], atol=FREE_TOL, rtol=0)
+      np.testing.assert_allclose(gate_g[b, :n].cpu().numpy(), gate_o[:n], atol=FREE_TOL, rtol=0)
+      np.testing.assert_allclose(align[b, :n, :ln].cpu().numpy(), align_o[:n], atol=FREE_TOL, rtol=0)
+      assert not mel[b, :, n:].any() and not align[b, :, ln:].any()
 
 
 def test_full_size_properties(gate_table):

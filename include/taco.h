@@ -180,6 +180,17 @@ int taco_encode_status(taco_handle h, void* stream);
 int taco_postnet(taco_handle h, const float* mel, const int32_t* n_frames, int32_t B, int32_t T_cap,
                  float* out, void* stream);
 
+/* taco_postnet for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same arguments and result as
+ * taco_postnet, but the layer activations live in a scratch area built into the library (8 MiB per device, held until
+ * the process ends) instead of the handle's grow-only workspace, and the call makes no hipMalloc / hipFree:
+ *   limit   B * max(C_post, n_mel) * T_cap <= 512 * TACO_NOALLOC_COLS floats, else TACO_EINVAL;
+ *   sharing every call on a device uses that device's one scratch area: calls that overlap on one GPU (two streams,
+ *           two handles) race; calls on one stream are ordered like any other work on it. */
+#define TACO_NOALLOC_COLS 2048
+int taco_postnet_noalloc(taco_handle h, const float* mel, const int32_t* n_frames, int32_t B, int32_t T_cap,
+                         float* out, void* stream);
+
 /* Device-side duration of the most recent taco_decode on this handle, measured with HIP events
  * recorded on the caller's stream around the persistent launch: writes microseconds in total and
  * the number of frames the longest utterance produced.  Synchronises on the stop event. */

@@ -22,6 +22,15 @@ void taco_set_error(const char* fmt, ...) {
 extern "C" const char* taco_last_error(void) { return g_err; }
 extern "C" const char* taco_version(void) { return "taco-hip 0.1 gfx950"; }
 
+// ---- scratch of the entry point that allocates nothing (taco_postnet_noalloc) ----
+// Two activation buffers of up to TACO_NOALLOC_COLS columns x 512 channels each, inside the code object: every device
+// the library runs on holds its own copy (8 MiB) until the process ends.  The name below is a host-side stand-in, not
+// a device address: taco_create asks for the address once per device, with that device current, and every use goes
+// through the pointer kept here.
+#define TACO_NOALLOC_HALF (512u * (unsigned)TACO_NOALLOC_COLS)
+static __device__ __align__(256) float taco_noalloc_scratch[2u * TACO_NOALLOC_HALF];
+static float* g_noalloc_ptr[64] = {nullptr};
+
 namespace {
 
 __global__ void taco_bn_fold_kernel(const float* w, const float* b, const float* mean, const float* var, float* alpha,
@@ -101,6 +110,11 @@ extern "C" int taco_create(const taco_dims* dims, const taco_weights* weights, i
   TACO_HIP(hipGetDeviceProperties(&prop, device));
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) TACO_FAIL(TACO_EINVAL, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
 
+  if (device >= 0 && device < 64 && !g_noalloc_ptr[device]) {
+    float* ptr = nullptr;
+    TACO_HIP(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(taco_noalloc_scratch)));
+    g_noalloc_ptr[device] = ptr;
+  }
   taco_handle h = new (std::nothrow) taco_handle_s();
   if (!h) TACO_FAIL(TACO_ENOMEM, "out of host memory");
   memset(h, 0, sizeof(*h));
@@ -496,6 +510,38 @@ extern "C" int taco_postnet(taco_handle h, const float* mel, const int32_t* n_fr
     float* dst = last ? out : h->ws_act[cur];
     rc = taco_launch_conv(cur_in, dst, h->w.post_conv_w[l], h->w.post_conv_b[l], h->post_alpha[l], h->post_beta[l],
                           last ? mel : nullptr, n_frames, B, c_in, c_out, d.k_post, T_cap, last ? 0 : /*tanh*/ 2, 0, s);
+    if (rc != TACO_OK) return rc;
+    cur_in = dst;
+    cur ^= 1;
+  }
+  return TACO_OK;
+}
+
+extern "C" int taco_postnet_noalloc(taco_handle h, const float* mel, const int32_t* n_frames, int32_t B, int32_t T_cap,
+                                    float* out, void* stream) {
+  if (!h || !mel || !out) TACO_FAIL(TACO_EINVAL, "taco_postnet_noalloc: NULL argument");
+  if (B < 1 || T_cap < 1) TACO_FAIL(TACO_EINVAL, "taco_postnet_noalloc: B = %d, T_cap = %d", B, T_cap);
+  hipStream_t s = (hipStream_t)stream;
+  const taco_dims& d = h->d;
+  const int cmax = d.C_post > d.n_mel ? d.C_post : d.n_mel;
+  if ((uint64_t)B * (uint64_t)cmax * (uint64_t)T_cap > (uint64_t)TACO_NOALLOC_HALF)
+    TACO_FAIL(TACO_EINVAL, "taco_postnet_noalloc: B * channels * T_cap = %d * %d * %d exceeds the built-in scratch of %u floats per "
+                           "buffer (%d columns of 512 channels); use taco_postnet", B, cmax, T_cap, TACO_NOALLOC_HALF, TACO_NOALLOC_COLS);
+  DeviceScope on_device(h->device);
+  TACO_HIP(on_device.status);
+  float* scratch = (h->device >= 0 && h->device < 64) ? g_noalloc_ptr[h->device] : nullptr;
+  if (!scratch) TACO_FAIL(TACO_EINVAL, "taco_postnet_noalloc: no scratch address for device %d", h->device);
+  float* buf[2] = {scratch, scratch + TACO_NOALLOC_HALF};
+  const float* cur_in = mel;
+  int cur = 0;
+  for (int l = 0; l < d.n_post; ++l) {
+    const bool last = l == d.n_post - 1;
+    const int c_in = l == 0 ? d.n_mel : d.C_post, c_out = last ? d.n_mel : d.C_post;
+    float* dst = last ? out : buf[cur];
+    // every layer writes all B x c_out x T_cap elements of its output (zeros at or past n_frames[b]), so nothing of the
+    // scratch's previous contents is ever read
+    const int rc = taco_launch_conv(cur_in, dst, h->w.post_conv_w[l], h->w.post_conv_b[l], h->post_alpha[l], h->post_beta[l],
+                                    last ? mel : nullptr, n_frames, B, c_in, c_out, d.k_post, T_cap, last ? 0 : /*tanh*/ 2, 0, s);
     if (rc != TACO_OK) return rc;
     cur_in = dst;
     cur ^= 1;

@@ -2,7 +2,8 @@
 reference's own outputs (tests/golden).  Needs a real MI355X: every test is marked ``gpu``.
 
 Tolerances (fp32 everywhere, absolute, on the log-mel scale; summation orders differ):
-  * teacher-forced frames vs the reference:   mel 1e-4, gate 1e-4, alignments 1e-4
+  * teacher-forced frames vs the reference:   mel 1e-4, gate 1e-4, alignments 1e-4 (goldens of up to 171 frames);
+    over the benchmark's 1000 frames: mel 1e-4, gate 1e-4 (batch-1 kernel) / 2e-4 (lockstep kernel), alignments 5e-4
   * encoder outputs vs the oracle:            1e-4
   * postnet vs the oracle on the same input:  2e-4
   * free-running: the stop frame index must be IDENTICAL to the reference's; frames 1e-3
@@ -96,6 +97,54 @@ def test_decoder_teacher_forced_matches_reference(name):
   np.testing.assert_allclose(align[0].cpu().numpy(), align_o[0], atol=TF_TOL, rtol=0)
 
 
+def test_benchmark_configuration_teacher_forced_over_1000_frames(monkeypatch):
+  """The benchmark's own workload (North-Wind line, LJS-sized model, 1000 frames, stop test off) pinned to the reference:
+  fed the reference's recorded frames, the batch-1 kernel and the lockstep kernel (the line among fifteen others)
+  reproduce all 1000 frames and stop energies to 1e-4 (alignments, which carry the drift of the unforced recurrent state
+  of this random-weight model, to 5e-4)."""
+  z, meta = load_golden("ljs_1000")
+  gm = gpu_model(meta["scenario"], meta["gate"])
+  ck = scenario_checkpoint(meta["scenario"], meta["gate"])
+  ids1 = golden_ids(z)
+  n, stride = meta["n_frames"], meta["align_stride"]
+  masks = prenet_keep_masks(meta["seed"], n, gm.dims.P)
+  mem, pm = gm.encode([dev(c) for c in chans(ids1)], dev(ids1["speakers"]), None)
+  forced = dev(z["mel"][None])
+  mel, gate, align, nf, reached = gm.decode(mem, pm, None, masks, n, forced_mel=forced, gate_threshold=meta["gate_threshold"])
+  assert int(nf[0]) == n
+  np.testing.assert_allclose(mel[0].cpu().numpy(), z["mel"], atol=TF_TOL, rtol=0)
+  np.testing.assert_allclose(gate[0].cpu().numpy(), z["gate"], atol=TF_TOL, rtol=0)
+  np.testing.assert_allclose(align[0, ::stride].cpu().numpy(), z["alignments_every_50"], atol=5e-4, rtol=0)
+  post = gm.postnet(mel, nf)
+  np.testing.assert_allclose(post[0, :, ::stride].cpu().numpy(), z["mel_postnet_every_50"], atol=2e-4, rtol=0)
+  # lockstep: the line in slots 0 and 9 of a group of 16 (the others: random lines forced with zeros)
+  T1 = ids1["symbols"].shape[1]
+  lens = [T1] + [int(v) for v in np.random.RandomState(3).randint(20, 201, size=15)]
+  lens[9] = T1
+  ids = scenarios.random_ids(ck, lens, seed=99)
+  for b in (0, 9):
+    for k in ("symbols", "stresses", "tones", "durations", "speakers"):
+      if ids[k] is not None:
+        ids[k][b, :T1] = ids1[k][0]
+  for b in range(16):
+    ids["speakers"][b, :] = ids["speakers"][b, 0]
+  lens_d = dev(np.array(lens, np.int32))
+  memb, pmb = gm.encode([dev(c) for c in chans(ids)], dev(ids["speakers"]), lens_d)
+  forced_b = torch.zeros(16, gm.dims.n_mel, n, device="cuda:0")
+  forced_b[0] = forced[0]
+  forced_b[9] = forced[0]
+  monkeypatch.setenv("TACO_DECODER", "lockstep")
+  melb, gateb, alignb, nfb, _ = gm.decode(memb, pmb, lens_d, masks, n, forced_mel=forced_b, gate_threshold=meta["gate_threshold"])
+  assert nfb.cpu().tolist() == [n] * 16
+  for b in (0, 9):
+    np.testing.assert_allclose(melb[b].cpu().numpy(), z["mel"], atol=TF_TOL, rtol=0)
+    # (stop energies: 2e-4 here; the lockstep kernel's exchanged values carry a 2-bit tag in their lowest mantissa bits,
+    # and over 1000 unforced recurrent frames 5 of the 1000 energies come out 1.1e-4 off)
+    np.testing.assert_allclose(gateb[b].cpu().numpy(), z["gate"], atol=2e-4, rtol=0)
+    np.testing.assert_allclose(alignb[b, ::stride, :T1].cpu().numpy(), z["alignments_every_50"], atol=5e-4, rtol=0)
+  assert bool(torch.isfinite(melb).all())
+
+
 @pytest.mark.parametrize("name", ["tiny", "ljs", "thchs"])
 def test_free_running_stop_frame_identical_to_reference(name):
   z, meta = load_golden(name)
@@ -173,6 +222,8 @@ def test_synthesizer_matches_reference_records(gate_table):
     np.testing.assert_allclose(res.mel_outputs_postnet, z["mel_postnet"], atol=FREE_TOL, rtol=0)
     np.testing.assert_allclose(res.mel_outputs, z["mel"], atol=FREE_TOL, rtol=0)
     assert res.gate_outputs.shape == z["gate"].shape and res.alignments.shape == z["alignments"].shape
+    np.testing.assert_allclose(res.gate_outputs, z["gate"], atol=FREE_TOL, rtol=0)
+    np.testing.assert_allclose(res.alignments, z["alignments"], atol=FREE_TOL, rtol=0)
     plain = s.infer(tuple(meta["symbols"]), meta["speaker"], max_decoder_steps=meta["max_steps"], seed=meta["seed"])
     assert plain.mel_outputs is None and plain.gate_outputs is None and plain.alignments is None
     assert np.array_equal(plain.mel_outputs_postnet, res.mel_outputs_postnet)    # deterministic

@@ -61,6 +61,26 @@ def test_teacher_forcing_reproduces_reference_frames():
   np.testing.assert_allclose(gate[0, :, 0], z["gate"], atol=TOL["gate"], rtol=0)
 
 
+def test_teacher_forcing_over_the_benchmark_configuration():
+  """The benchmark's own workload - the North-Wind line, LJS-sized model, 1000 frames with the stop test off - as the
+  reference computed it: fed the reference's frames back, the checker reproduces all 1000 of them."""
+  z, meta = load_golden("ljs_1000")
+  om = oracle_model(meta["scenario"], meta["gate"])
+  n = meta["n_frames"]
+  assert n == 1000 and z["mel"].shape == (om.dims.n_mel, n)
+  ids = golden_ids(z)
+  mem, pm = om.encode([ids[k] for k in ("symbols", "stresses", "tones", "durations") if ids[k] is not None], ids["speakers"], None)
+  masks = prenet_keep_masks(meta["seed"], n, om.dims.P).numpy()
+  mel, gate, align, nf, reached, _ = om.decode(mem, pm, None, masks, n, forced_mel=np.ascontiguousarray(z["mel"][None]),
+                                               gate_threshold=meta["gate_threshold"])
+  assert int(nf[0]) == n
+  np.testing.assert_allclose(mel[0], z["mel"], atol=1e-4, rtol=0)
+  np.testing.assert_allclose(gate[0], z["gate"], atol=1e-4, rtol=0)
+  # (frames and stop energies to 1e-4 over all 1000 frames; the recurrent state is not forced, and the sharply peaked
+  # attention weights of this random-weight model carry its drift: 5e-4 for them)
+  np.testing.assert_allclose(align[0, ::meta["align_stride"]], z["alignments_every_50"], atol=5e-4, rtol=0)
+
+
 @pytest.mark.parametrize("name", ["tiny_batch", "ljs_batch"])
 def test_padded_batch_equals_independent_reference_runs(name):
   z, meta = load_golden(name)

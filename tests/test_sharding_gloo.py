@@ -114,4 +114,6 @@ def test_bench_rank_plumbing_rehearsal():
   assert len(lines) == 1
   out = json.loads(lines[0])
   assert out["n_gpus"] == 2 and out["steps"] == 5 and out["rehearsal"] is True
+  # the sharded line set of the multi-GPU workload: every line in exactly one rank's shard, shards of equal size here
+  assert out["lines"] == 512 and out["lines_covered_once"] is True and 200 <= out["rank0_lines"] <= 312
   assert out["ms_per_step"] >= 4.0          # rank 1 sleeps 4 ms per step, rank 0 only 2 ms

@@ -295,6 +295,25 @@ def main(argv):
     case_synthesizer("ljs_synth_unmappable", "ljs", biases["ljs"], odd, "Linda Johnson", 0, 40)
   if on("ljs_batch"):
     case_batch("ljs_batch", "ljs", biases["ljs"], lens=[61, 40, 33], ids_seed=303, seed=1111, max_steps=40)
+  if on("ljs_1000"):
+    # the benchmark's own configuration: the North-Wind line run to 1000 frames with the stop test switched off
+    # (threshold above any sigmoid); mel, stop energies and every 50th alignment row are kept
+    ckpt = scenarios.checkpoint("ljs", biases["ljs"])
+    ids = ids_from_symbols(ckpt, scenarios.NORTH_WIND_SYMBOLS, "Linda Johnson")
+    model = build_ref_model(ckpt)
+    model.decoder.gate_threshold = 2.0
+    t0 = time.perf_counter()
+    out = run_ref(model, single_ids(ids, 0), 1111, 1000, capture=False)
+    dt = time.perf_counter() - t0
+    assert out["mel"].shape[1] == 1000 and bool(out["reached"])
+    arrays = dict(mel=out["mel"], gate=out["gate"], alignments_every_50=out["alignments"][::50].copy(),
+                  mel_postnet_every_50=out["mel_postnet"][:, ::50].copy())
+    for k, v in ids.items():
+      if v is not None:
+        arrays["in_" + k] = v
+    save("ljs_1000", arrays, dict(scenario="ljs", gate=list(biases["ljs"]), seed=1111, max_steps=1000, n_frames=1000,
+                                  gate_threshold=2.0, align_stride=50, ref_seconds=dt, ref_threads=torch.get_num_threads(),
+                                  speaker="Linda Johnson", torch=torch.__version__))
   if on("thchs"):
     ckpt = scenarios.checkpoint("thchs")
     ids = ids_from_symbols(ckpt, scenarios.thchs_line(), "A38")

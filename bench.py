@@ -188,13 +188,25 @@ def batch64_record(model, ckpt, device, frames=600, reps=3):
   dec_s = float(np.mean(dec_us)) * 1e-6
   flops = sum(flops_per_frame(model.dims, t) for t in lens) * frames
   achieved = flops / dec_s / 1e12
+  counters, traffic, src = None, None, latest_profile("r*_lockstep_pmc.json")
+  if src:
+    prof = json.load(open(src))["derived"]
+    counters = {"source": os.path.relpath(src, ROOT),
+                "mfma_busy_share_of_simd_cycles": prof.get("mfma_busy_share_of_simd_cycles"),
+                "mfma_instructions_per_lockstep_frame": prof.get("SQ_INSTS_VALU_MFMA_F32_per_lockstep_frame"),
+                "issue_fraction_of_wave_cycles": prof.get("SQ_ACTIVE_INST_ANY_per_WAVE_CYCLE"),
+                "valu_issue_fraction": prof.get("SQ_ACTIVE_INST_VALU_per_WAVE_CYCLE"),
+                "scalar_issue_fraction": prof.get("SQ_ACTIVE_INST_SCA_per_WAVE_CYCLE")}
+    if prof.get("hbm_bytes_per_lockstep_frame"):
+      traffic = int(prof["hbm_bytes_per_lockstep_frame"]) * frames
   return {"workload": f"64 lines of {min(lens)}..{max(lens)} symbols in one padded batch, {frames} frames each, lockstep decoder "
                       "(16 utterances per persistent launch)",
           "value": round(total / dt, 1), "unit": "mel frames/s", "ms_per_batch": round(dt * 1e3, 3),
           "decoder_us_per_lockstep_frame": round(dec_s / (4 * frames) * 1e6, 3),
           "decoder_us_per_utterance_frame": round(dec_s / total * 1e6, 4),
           "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                       "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None, "kernel": "taco_decoder_batch_kernel",
+                       "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
+                       "traffic_source": counters and counters["source"], "counters": counters, "kernel": "taco_decoder_batch_kernel",
                        "flops_per_launch": int(flops / 4), "kernel_ms_per_launch": round(dec_s / 4 * 1e3, 4),
                        "note": "algorithmic FLOPs (2 x weights touched + attention, per utterance and frame) of the four launches "
                                "of a batch of 64 / their device time (HIP events on the launch stream); exact-f32 matrix-core "

@@ -141,7 +141,12 @@ int64_t taco_step_weight_bytes(taco_handle h);
 int taco_encode(taco_handle h, const int64_t* const* ids, const int64_t* speakers, const int32_t* lens,
                 int32_t B, int32_t T_in, float* memory, float* processed_memory, void* stream);
 
-/* Autoregressive decoder: all frames of all B utterances in one persistent launch.
+/* Autoregressive decoder: all frames of an utterance inside one persistent launch, no host round trip per frame.
+ * Utterances of up to 208 symbols are taken sixteen at a time, in caller order, by the lockstep kernel (one launch
+ * advances all sixteen frame by frame, their LSTM gate rows as matrix-core tiles); longer utterances, and an
+ * utterance left alone, each get a launch of the batch-1 kernel.  The launches of one call run back to back on
+ * `stream`; per utterance the result does not depend on how the batch was grouped beyond 1e-4 (free-running
+ * recurrence).  Environment: TACO_DECODER=single or =lockstep forces one kernel.
  * Replaces Decoder.inference (reference: src/tacotron/model.py:529-568, 454-491, 96-117, 136-141).
  *   memory, processed_memory, lens   as produced by / passed to taco_encode
  *                (the lengths are copied to the host once per call: a length outside 1..T_in is refused

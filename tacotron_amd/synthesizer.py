@@ -165,7 +165,11 @@ class Synthesizer:
       duration_s=spectrogram_duration_s(mel_post.shape[-1], self.hparams.filter_length, self.hparams.hop_length))
 
   def infer(self, symbols: Sequence[str], speaker: Optional[str], max_decoder_steps: int = 3000, seed: int = 0,
-            include_stats: bool = False) -> InferenceResult:
+            include_stats: bool = False, keep_on_device: bool = False) -> InferenceResult:
+    """One line, as the reference's ``Synthesizer.infer`` (src/tacotron/synthesizer.py:93-239).  With
+    ``keep_on_device`` the arrays of the result stay ``torch`` tensors on the synthesizer's device (same shapes
+    and dtypes) for a consumer on the same GPU, e.g. a vocoder: nothing is copied to the host, and the tensors
+    are ready on the device's current stream."""
     prep = self._prepare(symbols, speaker)
     init_global_seeds(seed)
 
@@ -186,7 +190,7 @@ class Synthesizer:
     seconds = time.perf_counter() - start
 
     def to_np(t):
-      return t.squeeze(0).cpu().numpy()
+      return t.squeeze(0) if keep_on_device else t.squeeze(0).cpu().numpy()
 
     res = self._result(prep, to_np(mel_post), reached, seconds)
     if include_stats:
@@ -194,10 +198,11 @@ class Synthesizer:
     return res
 
   def infer_batch(self, lines: Sequence[Sequence[str]], speaker: Optional[str], max_decoder_steps: int = 3000,
-                  seed: int = 0, include_stats: bool = False) -> List[InferenceResult]:
+                  seed: int = 0, include_stats: bool = False, keep_on_device: bool = False) -> List[InferenceResult]:
     """Synthesizes several lines in one padded batch; every line gets the result ``infer`` would
     give it (same seed for each, as the CLI reuses one seed for all lines:
-    src/tacotron_cli/inference.py:137-141).  ``inference_duration_s`` is the batch time / lines."""
+    src/tacotron_cli/inference.py:137-141).  ``inference_duration_s`` is the batch time / lines.
+    ``keep_on_device``: as in ``infer``; each line's arrays are views into the batch's device tensors."""
     if len(lines) == 0:
       return []
     preps = [self._prepare(line, speaker) for line in lines]
@@ -228,13 +233,16 @@ class Synthesizer:
     seconds = (time.perf_counter() - start) / len(preps)
     n_frames = n_frames.cpu().tolist()
     reached = reached.cpu().tolist()
+    def hand(t):
+      return t if keep_on_device else t.cpu().numpy()
+
     out = []
     for b, p in enumerate(preps):
       n = n_frames[b]
-      res = self._result(p, post[b, :, :n].cpu().numpy(), bool(reached[b]), seconds)
+      res = self._result(p, hand(post[b, :, :n]), bool(reached[b]), seconds)
       if include_stats:
-        res.mel_outputs = mel[b, :, :n].cpu().numpy()
-        res.gate_outputs = gate[b, :n].unsqueeze(-1).cpu().numpy()
-        res.alignments = align[b, :n, :lens[b]].cpu().numpy()
+        res.mel_outputs = hand(mel[b, :, :n])
+        res.gate_outputs = hand(gate[b, :n].unsqueeze(-1))
+        res.alignments = hand(align[b, :n, :lens[b]])
       out.append(res)
     return out

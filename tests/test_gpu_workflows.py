@@ -1,0 +1,121 @@
+"""The commands and host-side entry points around the HIP path on a real MI355X (every test is marked ``gpu``):
+the bulk ``synthesize`` workload of many ragged lines in padded batches, ``synthesize-grids``, and results
+that stay on the device.  The checker is the CPU oracle behind the same host code (tests/oracle_shim.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden, scenario_checkpoint
+
+pytestmark = pytest.mark.gpu
+
+FREE_TOL = 1e-3          # free-running frames, absolute, log-mel scale (same bound as tests/test_gpu_parity.py)
+LONG_FREE_TOL = 5e-3     # free-running lines of up to 1000 frames: rounding differences grow with the frame index
+                         # (1.5e-3 seen at frame ~800 of a synthetic random-weight model); the first 200 frames keep 1e-3
+
+
+def _ragged_lines(ckpt, n, lo, hi, seed):
+  """n lines of lo..hi symbols drawn from the checkpoint's own symbol inventory, joined with '|'."""
+  keys = sorted(k for k in ckpt["symbol_mapping"].keys() if k and "|" not in k and k.strip() == k)
+  r = np.random.RandomState(seed)
+  lens = r.randint(lo, hi + 1, size=n)
+  return ["|".join(keys[i] for i in r.randint(0, len(keys), size=int(t))) for t in lens], [int(t) for t in lens]
+
+
+def test_bulk_synthesis_of_ragged_lines_in_batches_of_64(tmp_path, gate_table):
+  """The bulk workload at reduced line count: 320 synthetic lines, T_in ~ U{20..200}, through the synthesize
+  command with --batch-size 64 on the full-size (LJS-dimension) checkpoint with its calibrated stop token and
+  max_decoder_steps = 1000.  Every line must produce its file; lines that stop early, lines that run into the
+  step limit, and the longest and shortest lines are compared with the same command run with the CPU oracle as
+  its model (one line at a time): same file names, same frame counts, frames within the free-running bounds."""
+  from oracle_shim import oracle_synthesizer
+  from tacotron_amd import cli
+  from tacotron_amd.checkpoint import save_checkpoint
+  ckpt = scenario_checkpoint("ljs", gate_table["ljs"])
+  path = tmp_path / "ljs_synthetic.pt"
+  save_checkpoint(ckpt, path)
+  lines, lens = _ragged_lines(ckpt, 320, 20, 200, seed=2024)
+  text = tmp_path / "lines.txt"
+  text.write_text("\n".join(lines), encoding="UTF-8")
+  common = ["synthesize", str(path), str(text), "--sep", "|", "--custom-seed", "7", "--max-decoder-steps", "1000"]
+  ns = cli.build_parser().parse_args(common + ["-out", str(tmp_path / "gpu"), "--device", "cuda:0", "--batch-size", "64"])
+  assert ns.handler(ns)
+  files = sorted(p.name for p in (tmp_path / "gpu").iterdir())
+  assert files == [f"{i:03d}-{i:03d}.npy" for i in range(1, 321)]
+  frames = {}
+  for i, name in enumerate(files):
+    a = np.load(tmp_path / "gpu" / name, mmap_mode="r")
+    assert a.dtype == np.float32 and a.shape[0] == 80 and 1 <= a.shape[1] <= 1000
+    frames[i + 1] = a.shape[1]
+  at_limit = [nr for nr, n in frames.items() if n == 1000]
+  early = [nr for nr, n in frames.items() if n < 1000]
+  assert at_limit and early, "the workload is meant to hold both kinds of lines"
+  order = sorted(range(1, 321), key=lambda nr: lens[nr - 1])
+  sample = sorted({order[0], order[-1], at_limit[0], at_limit[-1], early[0], early[len(early) // 2], early[-1]})
+  ns = cli.build_parser().parse_args(common + ["-out", str(tmp_path / "oracle"), "--custom-lines"] + [str(nr) for nr in sample])
+  assert ns.handler(ns, synthesizer_factory=oracle_synthesizer)
+  assert sorted(p.name for p in (tmp_path / "oracle").iterdir()) == [f"{nr:03d}-{nr:03d}.npy" for nr in sample]
+  for nr in sample:
+    want, got = np.load(tmp_path / "oracle" / f"{nr:03d}-{nr:03d}.npy"), np.load(tmp_path / "gpu" / f"{nr:03d}-{nr:03d}.npy")
+    assert got.shape == want.shape, f"line {nr} ({lens[nr - 1]} symbols): {got.shape[1]} frames, the oracle has {want.shape[1]}"
+    np.testing.assert_allclose(got[:, :200], want[:, :200], atol=FREE_TOL, rtol=0, err_msg=f"line {nr}")
+    np.testing.assert_allclose(got, want, atol=LONG_FREE_TOL, rtol=0, err_msg=f"line {nr}")
+
+
+def test_synthesize_grids_on_gpu_matches_oracle_backed_run(tmp_path):
+  """synthesize-grids through the HIP library (reference: src/tacotron_cli/textgrid_inference.py:108-142): the files
+  the same command writes with the CPU oracle as its model, one grid at a time and in a padded batch."""
+  from oracle_shim import oracle_synthesizer
+  from test_textgrid import LONG, SHORT
+  from tacotron_amd import cli
+  ckpt = os.path.join(GOLDEN, "tiny_checkpoint.pt")
+  src = tmp_path / "grids"
+  (src / "sub").mkdir(parents=True)
+  (src / "one.TextGrid").write_text(LONG, encoding="UTF-8")
+  (src / "sub" / "two.textgrid").write_text(SHORT, encoding="UTF-8")
+  (src / "sub" / "broken.TextGrid").write_text("nothing", encoding="UTF-8")
+  common = ["synthesize-grids", ckpt, str(src), "symbols", "--seed", "5", "--max-decoder-steps", "15", "--speaker", "speaker1;en"]
+  ns = cli.build_parser().parse_args(common + ["-out", str(tmp_path / "oracle")])
+  assert ns.handler(ns, synthesizer_factory=oracle_synthesizer)
+  for sub, extra in (("gpu", []), ("gpu_batched", ["--batch-size", "2"])):
+    ns = cli.build_parser().parse_args(common + ["-out", str(tmp_path / sub), "--device", "cuda:0"] + extra)
+    assert ns.handler(ns)
+    files = sorted(str(p.relative_to(tmp_path / sub)) for p in (tmp_path / sub).rglob("*") if p.is_file())
+    assert files == ["one.npy", "sub/two.npy"]
+    for f in files:
+      want, got = np.load(tmp_path / "oracle" / f), np.load(tmp_path / sub / f)
+      assert got.shape == want.shape and got.dtype == np.float32
+      np.testing.assert_allclose(got, want, atol=FREE_TOL, rtol=0)
+
+
+def test_results_can_stay_on_the_device(gate_table):
+  """keep_on_device hands the result over as device tensors (for a vocoder on the same GPU) with the values,
+  shapes and dtypes of the host arrays; a consumer on the current stream reads them without a host copy."""
+  from tacotron_amd.synthesizer import Synthesizer
+  z, meta = load_golden("ljs_synth")
+  s = Synthesizer(scenario_checkpoint("ljs", meta["gate"]), device="cuda:0")
+  kw = dict(max_decoder_steps=meta["max_steps"], seed=meta["seed"], include_stats=True)
+  host = s.infer(tuple(meta["symbols"]), meta["speaker"], **kw)
+  on_dev = s.infer(tuple(meta["symbols"]), meta["speaker"], keep_on_device=True, **kw)
+  for name in ("mel_outputs_postnet", "mel_outputs", "gate_outputs", "alignments"):
+    a, b = getattr(host, name), getattr(on_dev, name)
+    assert isinstance(a, np.ndarray) and isinstance(b, torch.Tensor) and b.device == torch.device("cuda:0")
+    assert tuple(b.shape) == a.shape and b.dtype == torch.float32
+    assert np.array_equal(b.cpu().numpy(), a)
+  assert on_dev.duration_s == host.duration_s and on_dev.reached_max_decoder_steps == host.reached_max_decoder_steps
+  np.testing.assert_allclose(on_dev.mel_outputs_postnet.cpu().numpy(), z["mel_postnet"], atol=FREE_TOL, rtol=0)
+  # a consumer on the same stream: no synchronisation between the call and the use
+  energy = torch.logsumexp(on_dev.mel_outputs_postnet, dim=0)
+  assert energy.shape == (host.mel_outputs_postnet.shape[1],)
+  np.testing.assert_allclose(energy.cpu().numpy(), torch.logsumexp(torch.from_numpy(host.mel_outputs_postnet), dim=0).numpy(), atol=1e-5)
+  # batched: each line's arrays are device views with the values of the host arrays
+  lines = [tuple(meta["symbols"]), tuple(meta["symbols"][:40]), tuple(meta["symbols"][10:90])]
+  hb = s.infer_batch(lines, meta["speaker"], **kw)
+  db = s.infer_batch(lines, meta["speaker"], keep_on_device=True, **kw)
+  for h, d in zip(hb, db):
+    for name in ("mel_outputs_postnet", "mel_outputs", "gate_outputs", "alignments"):
+      a, b = getattr(h, name), getattr(d, name)
+      assert isinstance(b, torch.Tensor) and b.is_cuda and tuple(b.shape) == a.shape
+      assert np.array_equal(b.cpu().numpy(), a)

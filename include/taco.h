@@ -142,11 +142,12 @@ int taco_encode(taco_handle h, const int64_t* const* ids, const int64_t* speaker
                 int32_t B, int32_t T_in, float* memory, float* processed_memory, void* stream);
 
 /* Autoregressive decoder: all frames of an utterance inside one persistent launch, no host round trip per frame.
- * Utterances of up to 208 symbols are taken sixteen at a time, in caller order, by the lockstep kernel (one launch
- * advances all sixteen frame by frame, their LSTM gate rows as matrix-core tiles); longer utterances, and an
- * utterance left alone, each get a launch of the batch-1 kernel.  The launches of one call run back to back on
- * `stream`; per utterance the result does not depend on how the batch was grouped beyond 1e-4 (free-running
- * recurrence).  Environment: TACO_DECODER=single or =lockstep forces one kernel.
+ * Utterances of up to 208 symbols go through the lockstep kernel: ONE launch advances sixteen of them frame by frame
+ * (their LSTM gate rows as matrix-core tiles), and when one stops the next utterance of the call takes its slot, so
+ * a large B keeps all sixteen slots busy; an utterance's result there is bit-identical whatever else is in the call.
+ * Longer utterances, and an utterance left alone, each get a launch of the batch-1 kernel (same results to 1e-4
+ * under teacher forcing).  The launches of one call run back to back on `stream`.
+ * Environment: TACO_DECODER=single or =lockstep forces one kernel.
  * Replaces Decoder.inference (reference: src/tacotron/model.py:529-568, 454-491, 96-117, 136-141).
  *   memory, processed_memory, lens   as produced by / passed to taco_encode
  *                (the lengths are copied to the host once per call: a length outside 1..T_in is refused

@@ -450,8 +450,8 @@ extern "C" int taco_decode(taco_handle h, const float* memory, const float* proc
     for (int b = 0; b < B; ++b)
       if (host_lens[b] < 1 || host_lens[b] > T_in) TACO_FAIL(TACO_EINVAL, "taco_decode: lens[%d] = %d is outside 1..T_in=%d", b, host_lens[b], T_in);
   }
-  // Which decoder runs what.  Utterances of up to TACO_BT_TIN symbols go, sixteen at a time in the caller's order,
-  // through the lockstep kernel (one persistent launch per group); a lone utterance and the long ones run the
+  // Which decoder runs what.  Utterances of up to TACO_BT_TIN symbols go through the lockstep kernel - one persistent
+  // launch for all of them, sixteen in flight, in the caller's order; a lone utterance and the long ones run the
   // batch-1 kernel, one launch each.  TACO_DECODER=single / lockstep in the environment forces one of them
   // (lockstep still only for utterances within its capacity).
   int min_group = 2;
@@ -471,9 +471,9 @@ extern "C" int taco_decode(taco_handle h, const float* memory, const float* proc
     fits.clear();
   }
   int n_launches = 0;
-  for (size_t i0 = 0; i0 < fits.size(); i0 += TACO_BATCH_NB) {
-    const int n = (int)(fits.size() - i0 < (size_t)TACO_BATCH_NB ? fits.size() - i0 : TACO_BATCH_NB);
-    const int rc = taco_launch_decoder_batch(h, memory, processed_memory, T_in, lens, fits.data() + i0, n, n_launches, masks, T_cap,
+  if (!fits.empty()) {
+    // one launch for all of them: the kernel itself walks the utterances in index order, skipping those beyond its capacity
+    const int rc = taco_launch_decoder_batch(h, memory, processed_memory, T_in, lens, B, (int)fits.size(), n_launches, masks, T_cap,
                                              max_steps, gate_threshold, forced_mel, mel, gate, align, n_frames, reached_max, s);
     if (rc != TACO_OK) return rc;
     ++n_launches;

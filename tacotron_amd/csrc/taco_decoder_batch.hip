@@ -42,9 +42,14 @@
 // A frame's chain: dh, ctx -> h1 (P) -> p (P) -> attention LSTM (all) -> ah -> energies (Q) -> partial
 // energies (Q to Q) -> softmax, context (Q) -> ctx -> decoder LSTM (all) -> dh.  Products that nobody
 // waits for (next frame's attention-LSTM columns, the recurrent columns) run in the shadows of the hops.
-// An utterance that has stopped keeps its slot (its values stay finite and are no longer written out);
-// empty slots of a group run as copies of its first utterance; the launch ends when every utterance has
-// stopped or max_steps frames have been produced.
+// Slots refill: when an utterance stops (stop token, or max_steps frames), its slot takes the next utterance of the
+// call that fits the kernel - every workgroup sees the same stop tokens and keeps the same books, so all agree on
+// who sits where without talking - and that utterance starts from the initial state at the next lockstep frame that
+// is a multiple of four while the other fifteen carry on.  Columns of a tile never mix, and with starts on multiples
+// of four an utterance's words carry the same tag bits whenever it runs (the tags have period four), so its result is
+// bit for bit the same whatever its slot, its neighbours or its start.  With nobody left to take a slot the slot decodes on with its outputs
+// switched off (its values stay finite); slots never filled run as copies of the first utterance; the launch ends
+// when no slot holds a live utterance.
 #include "taco_device.h"
 
 #include <math.h>
@@ -87,8 +92,7 @@ static_assert(NL_H % BURST == 0 && NL_P == BURST, "burst structure");
 constexpr int L_RED = 0;                         // [4 waves][64 lanes][4]: partial tiles of an LSTM stage
 constexpr int L_BIAS = L_RED + NW * 256;         // [2 cells][4 units][4 gates]
 constexpr int L_STOP = L_BIAS + 32;              // stop tokens of the previous frame [16], failure flag at +16
-constexpr int L_UTT = L_STOP + 32;               // utterance index of every slot [16] (int)
-constexpr int L_ROLE = L_UTT + 16;
+constexpr int L_ROLE = L_STOP + 32;
 // P: folded layer-1 rows [400 k-steps][64], layer-2 rows [64][64], plain layer-1 rows [20][64], partial tiles, bias
 constexpr int KS_HC = (KH + KC) / 4;             // 400 k-steps of [dh ; ctx]
 constexpr int LP_WF = L_ROLE;
@@ -121,8 +125,8 @@ static_assert(L_TOTAL * 4 <= 160 * 1024, "batched decoder LDS carve exceeds a CU
 
 struct BatArgs {
   int P, M, Ra, Rd, A, K, n_mel, T_in, n_wg;
-  int n_utts;
-  int utt[NB];             // utterance index (into lens, memory, outputs) of every slot
+  int B;                   // utterances of the call; those of at most TACO_BT_TIN symbols are decoded here, in index order
+  int t_limit;             // lockstep frames after which the launch ends whatever its books say (never reached)
   const int32_t* lens;     // device, or NULL = T_in symbols each
   const float *prenet_w1, *prenet_w2, *wf_h, *wf_c, *wf_b, *att_w_ih, *att_w_hh, *att_b_ih, *att_b_hh, *query_w, *v_w,
       *loc_fold, *dec_w_ih, *dec_w_hh, *dec_b_ih, *dec_b_hh, *proj_w, *proj_b, *gate_w, *gate_b;
@@ -292,8 +296,6 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
   const bool is_q = q_id >= 0 && q_id < NB * NQ;          // empty slots run as copies of utterance 0, unwritten
   const int q_slot = is_q ? q_id / NQ : 0;
   const int dg = is_q ? q_id % NQ : 0;
-  const int q_b = a.utt[q_slot];                          // my utterance (Q)
-  const int len = is_q ? (a.lens ? min(a.lens[q_b], a.T_in) : a.T_in) : 0;
   const int q_base = dg * qd;
   const int q_cnt = is_q ? max(0, min(qd, A - q_base)) : 0;
   const int cw = MEMW;                                    // memory columns per Q workgroup (the last ones may lie beyond M: zeros)
@@ -331,7 +333,34 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
     if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
   }
 #undef BT_K
-  if (tid < NB) reinterpret_cast<int*>(lds + L_UTT)[tid] = a.utt[tid];
+
+  // ---------------- who sits where ----------------
+  // Utterances are taken in index order, those too long for this kernel skipped (the host decodes them with the
+  // batch-1 kernel).  `cursor` and the books below move only on what the stop tokens say, which every workgroup reads
+  // alike: no word is exchanged about the assignment.
+  int cursor = 0;
+  auto next_utterance = [&]() -> int {
+    while (cursor < a.B) {
+      const int i = cursor++;
+      if ((a.lens ? a.lens[i] : a.T_in) <= TIN) return i;
+    }
+    return -1;
+  };
+  unsigned alive = 0;                          // slots holding an utterance that still produces frames
+  unsigned waiting = 0;                        // slots whose next utterance is booked and starts at the coming multiple of four
+  int utt_u = 0, t0_u = 0;                     // my column's slot: its utterance, and the lockstep frame that one started in
+  {
+    int first = 0;
+    for (int sl = 0; sl < NB; ++sl) {
+      const int nu = next_utterance();
+      if (sl == 0) first = nu < 0 ? 0 : nu;
+      if (nu >= 0) alive |= 1u << sl;
+      if (utt == sl) utt_u = nu >= 0 ? nu : first;
+    }
+  }
+  int q_b = __builtin_amdgcn_readlane(utt_u, q_slot);     // Q: my slot's utterance, its start frame, its length
+  int q_t0 = 0;
+  int len = 0;
   if (tid < 16) {     // biases as [unit][gate]
     const int u = tid >> 2, gt = tid & 3, hu = j * 4 + u;
     lds[L_BIAS + tid] = hu < Ra ? a.att_b_ih[gt * Ra + hu] + a.att_b_hh[gt * Ra + hu] : 0.0f;
@@ -381,14 +410,9 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
   }
   float vq[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   if (is_q) {
-    const float* mem_b = a.memory + (size_t)q_b * a.T_in * M;
     _Pragma("unroll 1") for (int e = tid; e < q_cnt * Ra; e += NT) {
       const int r = e / Ra, c = e % Ra;
       lds[LQ_ROWS + r * KH + c] = a.query_w[(size_t)(q_base + r) * Ra + c];
-    }
-    _Pragma("unroll 1") for (int e = tid; e < len * MEMW; e += NT) {
-      const int s = e / MEMW, cc = e % MEMW;
-      lds[LQ_MEM + e] = cc < c_cnt ? mem_b[(size_t)s * M + c0 + cc] : 0.0f;
     }
     _Pragma("unroll 1") for (int i = tid; i < LOC_KSTEPS * 64; i += NT) {
       const int m = i >> 6, l = i & 63;
@@ -413,7 +437,7 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
   // is weight (or cumulative weight) number 4 m + kq of the 2K taps, read from the halo-padded LDS copies.  The
   // processed memory is read again every frame (L2-resident, asked for before the products, added after them):
   // keeping it in registers would cost 16 of them for the whole launch.
-  const float* pm_lane = a.pm + (size_t)q_b * a.T_in * A + q_base + 4 * kq;      // + position * A
+  const float* pm_lane = a.pm + q_base + 4 * kq;      // + (utterance * T_in + position) * A: set when the slot is filled
   const bool pm_vec = (A & 3) == 0 && (q_base & 3) == 0 && q_cnt == QD;         // my 4 dimensions are one aligned 16-byte load
   auto load_pm = [&](int s, float (&out)[4]) {
     if (pm_vec) {
@@ -424,7 +448,21 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
       for (int r = 0; r < 4; ++r) out[r] = (s < len && 4 * kq + r < q_cnt) ? pm_lane[(size_t)s * A + r] : 0.0f;
     }
   };
-  if (is_q) {
+  // Q: what belongs to the utterance in my slot - its memory columns, no attention weights yet, the location term of
+  // zero weights (= the processed memory).  Runs at the start and whenever the slot takes a new utterance; the caller
+  // has a barrier behind it, and one in front (nobody still reads the old utterance's copies).
+  int len16 = 0, pe_n = 0;
+  auto fill_slot = [&]() {
+    len = a.lens ? min(a.lens[q_b], a.T_in) : a.T_in;
+    len16 = (len + 15) & ~15;
+    pe_n = max(0, min(4, (len16 / 2 - (tid & 31) + 31) / 32));
+    pm_lane = a.pm + (size_t)q_b * a.T_in * A + q_base + 4 * kq;
+    const float* mem_b = a.memory + (size_t)q_b * a.T_in * M;
+    _Pragma("unroll 1") for (int e = tid; e < len * MEMW; e += NT) {
+      const int s = e / MEMW, cc = e % MEMW;
+      lds[LQ_MEM + e] = cc < c_cnt ? mem_b[(size_t)s * M + c0 + cc] : 0.0f;
+    }
+    _Pragma("unroll 1") for (int i = tid; i < 2 * (TIN + 2 * HALO); i += NT) lds[LQ_AW + i] = 0.0f;     // weights and cumulative weights
 #pragma unroll
     for (int ti = 0; ti < QT; ++ti) {
       const int s = 16 * (wave + NW * ti) + utt;
@@ -434,7 +472,9 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
         *reinterpret_cast<float4*>(lds + LQ_U + s * QD + 4 * kq) = make_float4(pm0[0], pm0[1], pm0[2], pm0[3]);
       }
     }
-  }
+  };
+  if (is_q) fill_slot();
+  __syncthreads();
   // (lane_o: the lane number behind a compiler barrier, taken anew every frame, see BT_OPQ.)
   auto update_location_term = [&](int lane_o) {
     const int col = lane_o & 15, kqo = lane_o >> 4;
@@ -484,15 +524,11 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
   };
   // Q: partial energies are gathered by thread (group tid >> 5, l = tid & 31): pairs of granules l, l + 32, l + 64, l + 96
   // of that group's positions
-  const int len16 = (len + 15) & ~15;
-  const int pe_n = max(0, min(4, (len16 / 2 - (tid & 31) + 31) / 32));
   const unsigned pe_src0 = (unsigned)(a.lay.pe + 2 * ((q_slot * NQ + (tid >> 5)) * TIN + 2 * (tid & 31)));   // word index
 
   f32x4 acc_a = {0.0f, 0.0f, 0.0f, 0.0f};     // attention-LSTM partial over [context ; hidden] of the previous frame
   f32x4 acc_dn = {0.0f, 0.0f, 0.0f, 0.0f};    // decoder-LSTM partial over the previous decoder hidden state
   float c_a = 0.0f, c_d = 0.0f;               // cell states (wave 0: lane = (unit kq, utterance utt))
-  unsigned alive = a.n_utts >= 32 ? 0xffffffffu : ((1u << a.n_utts) - 1u);
-  int my_frames = 0;                           // thread tid < 16 of every workgroup: frames of utterance slot tid
   int t = 0;
   // word index of this lane's first load in each vector, replica `rep`
   const unsigned w_lane_h1 = (unsigned)(a.lay.h1 + rep * a.lay.h1_cap + utt * KP + 16 * (wave * NL_P) + 4 * kq);
@@ -522,13 +558,14 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
     const int utt_f = lane_f & 15, kq_f = lane_f >> 4;
 
     // ============ P: prenet layer 2 of this frame (heads the chain; does not wait for the stop test) ============
-    if (is_p && t < a.max_steps) {
+    if (is_p) {
       f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-      // keep bytes of the next frame, asked for a frame ahead (a first-touch line comes from HBM)
+      // keep bytes of my column's next frame (each utterance counts its own frames), asked for a frame ahead (a
+      // first-touch line comes from HBM)
       unsigned kn1 = 0, kn2 = 0;
       if (wave == 0) {
         const int r0 = min(j * RP + 4 * kq, P - 4);
-        const uint8_t* src = a.masks + (size_t)min(t + 1, a.max_steps - 1) * 2 * P + r0;
+        const uint8_t* src = a.masks + (size_t)max(0, min(t - t0_u + 1, a.max_steps - 1)) * 2 * P + r0;
         kn1 = *reinterpret_cast<const unsigned*>(src);
         kn2 = *reinterpret_cast<const unsigned*>(src + P);
       }
@@ -567,6 +604,7 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
 
     BT_STAMP(0);
     // ============ frame boundary: the previous frame's stop tokens ============
+    unsigned fresh = 0;                         // slots whose utterance starts with this frame
     if (t > 0) {
       const taco_granule* g_stop = reinterpret_cast<const taco_granule*>(a.words + (((t - 1) & 1) ? a.lay.per_parity : 0) + a.lay.stop + rep * a.lay.stop_cap);
       if (wave == 0 && lane < NB) lds[L_STOP + lane] = taco_wait_one(g_stop, lane, (unsigned)t, wctx, 0x100u);
@@ -575,11 +613,55 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
       if (lds[L_STOP + 16] != 0.0f) break;
       const bool fired = !forced && taco_sigmoid(lds[L_STOP + utt]) > a.thr;
       const unsigned fmask = (unsigned)__ballot(fired) & 0xffffu;
-      const unsigned ended = alive & fmask;
-      if (tid < NB && ((ended >> tid) & 1u)) my_frames = t;
-      alive &= ~fmask;
+      const unsigned lmask = (unsigned)__ballot(t - t0_u >= a.max_steps) & 0xffffu;
+      unsigned ended = alive & (fmask | lmask);
+      alive &= ~ended;
+      while (ended) {
+        // the slot's utterance is complete (the stopping frame is kept); the next one that fits is booked for the slot
+        // and starts at the next frame that is a multiple of four (see the head of the file)
+        const int sl = __builtin_ctz(ended);
+        ended &= ended - 1u;
+        const int done = __builtin_amdgcn_readlane(utt_u, sl), done_t0 = __builtin_amdgcn_readlane(t0_u, sl);
+        if (j == 0 && tid == 0) {
+          a.n_frames[done] = t - done_t0;
+          a.reached[done] = (uint8_t)((((fmask >> sl) & 1u) == 0u && !forced) ? 1u : 0u);
+        }
+        const int nu = next_utterance();
+        if (nu >= 0) {
+          waiting |= 1u << sl;
+          if (utt == sl) { utt_u = nu; t0_u = (t + 3) & ~3; }
+        }
+      }
+      if ((t & 3) == 0 && waiting) {
+        fresh = waiting;
+        alive |= waiting;
+        waiting = 0u;
+      }
+      if (fresh) {
+        // a slot's new utterance starts from the initial state: nothing carried over from the frame before in its
+        // column (partial sums over the previous hidden states and context, cell states; the prenet output of its
+        // first frame is zeroed where it is consumed)
+        if ((fresh >> utt) & 1u) {
+          acc_a = {0.0f, 0.0f, 0.0f, 0.0f};
+          acc_dn = {0.0f, 0.0f, 0.0f, 0.0f};
+          c_a = 0.0f;
+          c_d = 0.0f;
+          if (is_p && wave == 0) {
+            const int r0 = min(j * RP + 4 * kq, P - 4);
+            const uint8_t* src = a.masks + (size_t)min(1, a.max_steps - 1) * 2 * P + r0;
+            keep_l1 = *reinterpret_cast<const unsigned*>(src);
+            keep_next = *reinterpret_cast<const unsigned*>(src + P);
+          }
+        }
+        if (is_q && ((fresh >> q_slot) & 1u)) {
+          q_b = __builtin_amdgcn_readlane(utt_u, q_slot);
+          q_t0 = t;
+          fill_slot();
+          taco_lds_barrier();
+        }
+      }
     }
-    if (alive == 0u || t == a.max_steps) break;
+    if ((alive | waiting) == 0u || t >= a.t_limit) break;
     BT_STAMP(1);
 
     // ============ attention LSTM ============
@@ -592,6 +674,12 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
       bt_issue<NL_P>(rs, par + w_lane_p, v);
       bt_check<NL_P, 0, NL_P>(rs, par + w_lane_p, tag, v, wctx, 0x400u);
       nap_p = taco_nap_adjust(nap_p, wctx.spun);
+      if (fresh) {           // the first frame of an utterance is fed the all-zero frame: its prenet output is zero
+        if ((fresh >> utt) & 1u) {
+#pragma unroll
+          for (int i = 0; i < NL_P; ++i) v[i] = u32x4{0u, 0u, 0u, 0u};
+        }
+      }
       BT_STAMP(2);
       f32x4 acc2 = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -727,7 +815,7 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
         nap_pe = taco_nap_adjust(nap_pe, wctx.spun);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-          if (i < pe_n) *reinterpret_cast<float2*>(lds + pd + 64 * i) = make_float2(BT_F(v[i].x), BT_F(v[i].z));
+          if (i < pe_n) *reinterpret_cast<float2*>(lds + pd + 64 * i) = make_float2(__uint_as_float(v[i].x), __uint_as_float(v[i].z));     // {value, epoch} granules: exact values
       }
       taco_lds_barrier();
       BT_STAMP(7);
@@ -760,7 +848,7 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
       if (tid < TIN) aw_t[0] = w_own;
       if (tid < len) {
         aw_t[LQ_CUM - LQ_AW] += w_own;
-        if (dg == 0 && a.align && ((alive >> q_slot) & 1u)) a.align[((size_t)q_b * a.T_cap + t) * a.T_in + tid] = w_own;
+        if (dg == 0 && a.align && ((alive >> q_slot) & 1u)) a.align[((size_t)q_b * a.T_cap + (t - q_t0)) * a.T_in + tid] = w_own;
       }
       taco_lds_barrier();
       // context columns: thread (column quad cg, position group pg) sums its positions for 4 columns; the 15 groups
@@ -898,7 +986,7 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
         BT_ROWS_BURST(0) BT_ROWS_BURST(1) BT_ROWS_BURST(2) BT_ROWS_BURST(3)
 #undef BT_ROWS_BURST
         acc_r += acc_r2;
-        if (is_p && forced && t + 1 < a.max_steps) {
+        if (is_p && forced) {
           // teacher forcing: the plain layer-1 rows on the given frame (wave w takes k-steps 5w .. 5w + 4)
           constexpr int W1_PER_WAVE = (W1_KSTEPS + NW - 1) / NW;
           const float* w1row = lds + BT_OPQ(LP_W1 + W1_PER_WAVE * wave * 64 + lane_f);
@@ -907,14 +995,14 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
             const int ks = W1_PER_WAVE * wave + i;
             const int k = 16 * (ks >> 2) + 4 * kq_f + (ks & 3);
             float xv = 0.0f;
-            if (ks < W1_KSTEPS && k < NMEL) xv = a.forced_mel[((size_t)reinterpret_cast<const int*>(lds + L_UTT)[utt_f] * NMEL + k) * a.T_cap + t];
+            if (ks < W1_KSTEPS && k < NMEL) xv = a.forced_mel[((size_t)utt_u * NMEL + k) * a.T_cap + max(0, min(t - t0_u, a.T_cap - 1))];
             if (ks < W1_KSTEPS) acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(w1row[i * 64], xv, acc_r, 0, 0, 0);
           }
         }
         const f32x4 sum = bt_reduce_tiles(lds, is_p ? LP_RED : LM_RED, acc_r, wave, lane_f);
         if (wave == 0) {
           if (is_p) {
-            if (t + 1 < a.max_steps) {
+            {
               const unsigned par_n = ((t + 1) & 1) ? (unsigned)a.lay.per_parity : 0u;
               const unsigned tag_n = ((((unsigned)t + 1u) >> 1) & 1u) + 1u;
               float hv1[4];
@@ -930,7 +1018,7 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
               keep_l2 = keep_next;
             }
           } else {
-            const int b_out = reinterpret_cast<const int*>(lds + L_UTT)[utt];
+            const int b_out = utt_u, tb = t - t0_u;      // my column's utterance and its own frame index
             const bool wr = (alive >> utt) & 1u;
             taco_granule* g_stop = reinterpret_cast<taco_granule*>(gw + a.lay.stop);
 #pragma unroll
@@ -938,11 +1026,11 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
               const int row = (j - n_p_wg) * RP + 4 * kq + r;
               const float v = sum[r] + lds[LM_BIAS + 4 * kq + r];
               if (row < NMEL) {
-                if (wr) a.mel[((size_t)b_out * NMEL + row) * a.T_cap + t] = v;
+                if (wr) a.mel[((size_t)b_out * NMEL + row) * a.T_cap + tb] = v;
               } else if (row == NMEL) {
 #pragma unroll
                 for (int rr = 0; rr < REP; ++rr) taco_publish(g_stop + (size_t)rr * (a.lay.stop_cap / 2), utt, ep, v);
-                if (wr) a.gate[(size_t)b_out * a.T_cap + t] = v;
+                if (wr) a.gate[(size_t)b_out * a.T_cap + tb] = v;
               }
             }
           }
@@ -972,17 +1060,9 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
     BT_STAMP(14);
   }
 
-  if (j == 0 && tid < a.n_utts) {
-    const bool was_alive = (alive >> tid) & 1u;
-    const int frames = was_alive ? t : my_frames;
-    const unsigned reached = (was_alive && !forced && t == a.max_steps) ? 1u : 0u;
-    const int b_out = reinterpret_cast<const int*>(lds + L_UTT)[tid];
-    a.n_frames[b_out] = frames;
-    a.reached[b_out] = (uint8_t)reached;
-    if (tid == 0) {
-      a.ctl->n_frames = (uint32_t)t;
-      a.ctl->reached_max = reached;
-    }
+  if (j == 0 && tid == 0) {
+    a.ctl->n_frames = (uint32_t)t;       // lockstep frames of the launch
+    a.ctl->reached_max = 0u;
   }
 }
 
@@ -1111,19 +1191,22 @@ void taco_decoder_batch_dump_stamps(int n_frames) {
 }
 #endif
 
-// One lockstep launch for the utterances utt[0..n) (n <= 16, every one of at most TACO_BT_TIN symbols).
+// One lockstep launch for all utterances of a call that fit the kernel (own length <= TACO_BT_TIN; `n_fit` of the B,
+// counted by the caller): sixteen at a time, a slot taking the next one as soon as its utterance has stopped.
 int taco_launch_decoder_batch(taco_handle h, const float* memory, const float* pm, int T_in, const int32_t* lens,
-                              const int* utt, int n, int group, const uint8_t* masks, int T_cap, int max_steps, float thr,
+                              int B, int n_fit, int group, const uint8_t* masks, int T_cap, int max_steps, float thr,
                               const float* forced_mel, float* mel, float* gate, float* align, int32_t* n_frames,
                               uint8_t* reached, hipStream_t s) {
   const taco_dims& d = h->d;
-  if (n < 1 || n > NB) TACO_FAIL(TACO_EINVAL, "lockstep group of %d utterances (1..%d)", n, NB);
+  if (n_fit < 1 || n_fit > B) TACO_FAIL(TACO_EINVAL, "lockstep launch for %d of %d utterances", n_fit, B);
+  if (!lens && T_in > TIN) TACO_FAIL(TACO_EINVAL, "lockstep launch: T_in = %d without lengths (capacity %d)", T_in, TIN);
   if (T_in < 1 || T_in > TACO_MAX_TIN) TACO_FAIL(TACO_EINVAL, "T_in = %d", T_in);
   if (max_steps < 1 || max_steps > T_cap) TACO_FAIL(TACO_EINVAL, "max_steps %d outside 1..T_cap=%d", max_steps, T_cap);
   BatArgs a;
   a.P = d.P; a.M = d.M; a.Ra = d.R_a; a.Rd = d.R_d; a.A = d.A; a.K = d.K; a.n_mel = d.n_mel; a.T_in = T_in; a.n_wg = TACO_BT_WGS;
-  a.n_utts = n;
-  for (int i = 0; i < NB; ++i) a.utt[i] = utt[i < n ? i : 0];
+  a.B = B;
+  const long long most = (long long)n_fit * (max_steps + 4) + 4;     // every lockstep frame is a frame of at least one utterance, or one of up to 3 before a start
+  a.t_limit = most > 0x7fffffffLL ? 0x7fffffff : (int)most;
   a.lens = lens;
   const taco_weights& w = h->w;
   a.prenet_w1 = w.prenet_w1; a.prenet_w2 = w.prenet_w2; a.wf_h = h->wf_h; a.wf_c = h->wf_c; a.wf_b = h->wf_b;

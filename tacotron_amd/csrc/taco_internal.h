@@ -171,7 +171,7 @@ int taco_launch_decoder(taco_handle h, const float* memory, const float* pm, int
 int taco_decoder_collect(taco_handle h, int n_launches, hipStream_t s);
 // lockstep decoder (taco_decoder_batch.hip)
 int taco_launch_decoder_batch(taco_handle h, const float* memory, const float* pm, int T_in, const int32_t* lens,
-                              const int* utt, int n, int launch_idx, const uint8_t* masks, int T_cap, int max_steps, float thr,
+                              int B, int n_fit, int launch_idx, const uint8_t* masks, int T_cap, int max_steps, float thr,
                               const float* forced_mel, float* mel, float* gate, float* align, int32_t* n_frames,
                               uint8_t* reached, hipStream_t s);
 size_t taco_decoder_batch_lds_bytes();

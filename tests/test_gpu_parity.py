@@ -487,6 +487,49 @@ def test_lockstep_groups_and_long_lines_mix(gate_table):
       assert not mel[b, :, n:].any() and not align[b, :, ln:].any()
 
 
+def test_lockstep_slots_refill_and_results_do_not_depend_on_neighbours(gate_table, monkeypatch):
+  """Fifty ragged lines with the stop test live through ONE lockstep launch: sixteen are in flight, and a slot whose
+  utterance stops takes the next line at the next lockstep frame that is a multiple of four.  Every line against the checker's run of it alone
+  (stop frame identical), and - the columns of a tile never mix, and the tag bits of the exchanged words follow the
+  utterance's own frame count - BIT-identical frames when the same lines are decoded in reverse order (other slots,
+  other neighbours, other start frames) and when a line is decoded with a single neighbour."""
+  gate = gate_table["ljs"]
+  gm = gpu_model("ljs", gate)
+  om = oracle_model("ljs", gate)
+  ck = scenario_checkpoint("ljs", gate)
+  r = np.random.RandomState(50)
+  lens = [int(v) for v in r.randint(3, 201, size=50)]
+  max_steps = 90
+  ids = scenarios.random_ids(ck, lens, seed=5050)
+  for b in range(len(lens)):
+    ids["speakers"][b, :] = ids["speakers"][b, 0]
+  masks = prenet_keep_masks(11, max_steps, gm.dims.P)
+  lens_d = dev(np.array(lens, np.int32))
+  mem, pm = gm.encode([dev(c) for c in chans(ids)], dev(ids["speakers"]), lens_d)
+  monkeypatch.setenv("TACO_DECODER", "lockstep")
+  mel, gate_g, align, nf, reached = gm.decode(mem, pm, lens_d, masks, max_steps)
+  frames = nf.cpu().tolist()
+  assert len(set(frames)) > 4 and min(frames) < max_steps and max(frames) == max_steps, "slots are meant to free up at different frames"
+  us, lockstep_frames = gm.last_decode_timing()
+  assert lockstep_frames < 0.6 * max_steps * ((len(lens) + 15) // 16), "freed slots were not taken over"
+  for b, ln in enumerate(lens):
+    _, mel_o, gate_o, align_o, n, reached_o = _oracle_single(om, ids, b, ln, masks, max_steps)
+    assert frames[b] == n and int(reached[b]) == reached_o, (b, ln, frames[b], n)
+    np.testing.assert_allclose(mel[b, :, :n].cpu().numpy(), mel_o[:, :n], atol=FREE_TOL, rtol=0)
+    np.testing.assert_allclose(gate_g[b, :n].cpu().numpy(), gate_o[:n], atol=FREE_TOL, rtol=0)
+    np.testing.assert_allclose(align[b, :n, :ln].cpu().numpy(), align_o[:n], atol=FREE_TOL, rtol=0)
+    assert not mel[b, :, n:].any() and not align[b, :, ln:].any() and not align[b, n:].any() and not gate_g[b, n:].any()
+  # the same lines in reverse order
+  flip = torch.arange(len(lens) - 1, -1, -1, device="cuda:0")
+  mel_r, gate_r, align_r, nf_r, reached_r = gm.decode(mem[flip].contiguous(), pm[flip].contiguous(), lens_d[flip].contiguous(), masks, max_steps)
+  assert torch.equal(nf_r[flip], nf) and torch.equal(reached_r[flip], reached)
+  assert torch.equal(mel_r[flip], mel) and torch.equal(gate_r[flip], gate_g) and torch.equal(align_r[flip], align)
+  # a line with one neighbour only
+  pick = torch.tensor([17, 3], device="cuda:0")
+  mel_2, gate_2, align_2, nf_2, _ = gm.decode(mem[pick].contiguous(), pm[pick].contiguous(), lens_d[pick].contiguous(), masks, max_steps)
+  assert torch.equal(mel_2, mel[pick]) and torch.equal(align_2, align[pick]) and torch.equal(nf_2, nf[pick])
+
+
 def test_full_size_properties(gate_table):
   """Size-independent checks at the benchmark's extents (1000 frames of the LJS-sized model):
   bit-reproducibility, the prefix property (fewer allowed steps = a prefix of the longer run),

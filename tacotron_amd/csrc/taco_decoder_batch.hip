@@ -25,10 +25,11 @@
 //     pair: an fp32 whose two lowest mantissa bits carry the generation of its slot (1 or 2, alternating
 //     between the uses of a slot; 0 = never written).  The consumer uses the word as it is - tag bits
 //     included, a relative perturbation of at most 2^-22, the same for everyone - and checks the tag
-//     bits of what it loaded.  Vectors are utterance-major ([utterance][k]) and are loaded straight into
+//     bits of what it loaded.  Vectors are laid out [k / 16][utterance][k % 16] and are loaded straight into
 //     MFMA B operands: lane (utterance u = l & 15, q = l >> 4) fetches 16 bytes = the words
 //     k = 16 i + 4 q .. + 3 of load i, its operands of four consecutive 4-deep steps (the weights are held
-//     in the same column order).  Every vector is fetched once per workgroup and frame;
+//     in the same column order); the 64 lanes of load i together read 1 KB of consecutive memory.  Every vector is
+//     fetched once per workgroup and frame;
 //   * the attention context is computed explicitly (the batch-1 kernel folds it into per-utterance
 //     weight rows, which a batch cannot share): 8 "Q" workgroups per utterance each hold 16 attention
 //     dimensions (query rows, location filter, location term) and an eighth of the memory columns;
@@ -207,7 +208,7 @@ __device__ __forceinline__ void bt_publish_units(__amdgpu_buffer_rsrc_t rs, unsi
 template <int N>
 __device__ __forceinline__ void bt_issue(__amdgpu_buffer_rsrc_t rs, unsigned widx, u32x4 (&v)[N]) {
 #pragma unroll
-  for (int i = 0; i < N; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (widx + 16u * i) * 4u, 0, 16 /* sc1 */);
+  for (int i = 0; i < N; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (widx + 256u * i) * 4u, 0, 16 /* sc1 */);
 }
 template <int N, int I0, int CNT>
 __device__ __forceinline__ void bt_check(__amdgpu_buffer_rsrc_t rs, unsigned widx, unsigned tag, u32x4 (&v)[N], taco_wait_ctx& ctx,
@@ -231,10 +232,14 @@ __device__ __forceinline__ void bt_check(__amdgpu_buffer_rsrc_t rs, unsigned wid
     }
     asm volatile("" ::: "memory");
 #pragma unroll
-    for (int i = I0; i < I0 + CNT; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (widx + 16u * i) * 4u, 0, 16);
+    for (int i = I0; i < I0 + CNT; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (widx + 256u * i) * 4u, 0, 16);
   }
 }
 #define BT_F(x) __uint_as_float(x)
+// Where value k of utterance slot u sits inside an exchanged vector: [k / 16][slot][k % 16].  One load instruction of a
+// wave (16 slots x 4 quarter-lanes x 16 bytes) then covers 1 KB of consecutive memory - eight whole cache lines, each
+// asked for once - instead of sixteen half lines that the next instruction asks for again.
+__device__ __forceinline__ constexpr unsigned bt_word(int k, int u) { return (unsigned)(((k >> 4) * NB + u) * 16 + (k & 15)); }
 
 // The waves' partial tiles -> LDS at float index `red`; after the barrier wave 0 holds the sum (other waves get their own
 // partial back).
@@ -531,11 +536,11 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
   float c_a = 0.0f, c_d = 0.0f;               // cell states (wave 0: lane = (unit kq, utterance utt))
   int t = 0;
   // word index of this lane's first load in each vector, replica `rep`
-  const unsigned w_lane_h1 = (unsigned)(a.lay.h1 + rep * a.lay.h1_cap + utt * KP + 16 * (wave * NL_P) + 4 * kq);
-  const unsigned w_lane_p = (unsigned)(a.lay.p + rep * a.lay.p_cap + utt * KP + 16 * (wave * NL_P) + 4 * kq);
-  const unsigned w_lane_ah = (unsigned)(a.lay.ah + rep * a.lay.ah_cap + utt * KH + 16 * (wave * NL_H) + 4 * kq);
-  const unsigned w_lane_dh = (unsigned)(a.lay.dh + rep * a.lay.dh_cap + utt * KH + 16 * (wave * NL_H) + 4 * kq);
-  const unsigned w_lane_c = (unsigned)(a.lay.ctx + rep * a.lay.ctx_cap + utt * KC + 16 * (wave * NL_C) + 4 * kq);
+  const unsigned w_lane_h1 = (unsigned)(a.lay.h1 + rep * a.lay.h1_cap) + bt_word(16 * (wave * NL_P) + 4 * kq, utt);
+  const unsigned w_lane_p = (unsigned)(a.lay.p + rep * a.lay.p_cap) + bt_word(16 * (wave * NL_P) + 4 * kq, utt);
+  const unsigned w_lane_ah = (unsigned)(a.lay.ah + rep * a.lay.ah_cap) + bt_word(16 * (wave * NL_H) + 4 * kq, utt);
+  const unsigned w_lane_dh = (unsigned)(a.lay.dh + rep * a.lay.dh_cap) + bt_word(16 * (wave * NL_H) + 4 * kq, utt);
+  const unsigned w_lane_c = (unsigned)(a.lay.ctx + rep * a.lay.ctx_cap) + bt_word(16 * (wave * NL_C) + 4 * kq, utt);
   const float4* ws_lane = a.wstream + ((size_t)(j * NW + wave) * (NL_P + NL_C)) * 64 + lane;   // load i: ws_lane[i * 64]
   unsigned keep_next = 0;                      // P, wave 0: keep bytes of my 4 rows, layer 0 (low) / layer 1 of the coming frame
   unsigned keep_l1 = 0, keep_l2 = 0;
@@ -595,7 +600,7 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
           v = ((keep_l2 >> (8 * r)) & 0xffu) ? v * 2.0f : 0.0f;
           pv[r] = row < P ? v : 0.0f;
         }
-        bt_store4<REP>(rs, par + (unsigned)(a.lay.p + utt * KP + j * RP + 4 * kq), a.lay.p_cap, tag, pv[0], pv[1], pv[2], pv[3]);
+        bt_store4<REP>(rs, par + (unsigned)a.lay.p + bt_word(j * RP + 4 * kq, utt), a.lay.p_cap, tag, pv[0], pv[1], pv[2], pv[3]);
         keep_l1 = kn1;
         keep_next = kn2;
       }
@@ -693,7 +698,7 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
         const f32x4 bias = *reinterpret_cast<const f32x4*>(lds + L_BIAS + 4 * kq_f);
         const float hv = bt_lstm_cell(pre, bias, c_a);
         const int hu = j * 4 + kq;
-        bt_publish_units<REP>(rs, par + (unsigned)(a.lay.ah + utt * KH + j * 4), a.lay.ah_cap, tag, hu < Ra ? hv : 0.0f, lane);
+        bt_publish_units<REP>(rs, par + (unsigned)a.lay.ah + bt_word(j * 4, utt), a.lay.ah_cap, tag, hu < Ra ? hv : 0.0f, lane);
       }
     }
     BT_STAMP(3);
@@ -703,10 +708,10 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
       {
         // the hidden state of my utterance: 1024 words, 16 bytes per thread
         u32x4 v[1];
-        const unsigned src = par + (unsigned)(a.lay.ah + rep * a.lay.ah_cap + q_slot * KH) + 4u * (unsigned)tid_f;
+        const unsigned src = par + (unsigned)(a.lay.ah + rep * a.lay.ah_cap) + bt_word(4 * tid_f, q_slot);
         bt_nap_begin(nap_ahq, wctx);
         v[0] = __builtin_amdgcn_raw_buffer_load_b128(rs, src * 4u, 0, 16);
-        // (the loop of bt_check fetches from widx + 16 i: with one load that is the same address)
+        // (the loop of bt_check fetches load i from widx + 256 i: with one load that is the same address)
         bt_check<1, 0, 1>(rs, src, tag, v, wctx, 0x500u);
         nap_ahq = taco_nap_adjust(nap_ahq, wctx.spun);
         *reinterpret_cast<float4*>(lds + BT_OPQ(LQ_XPE + 4 * tid_f)) = make_float4(BT_F(v[0].x), BT_F(v[0].y), BT_F(v[0].z), BT_F(v[0].w));
@@ -889,10 +894,10 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
           const float4 v = *reinterpret_cast<const float4*>(cp + pg * MEMW);
           s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
-        bt_store4<REP>(rs, par + (unsigned)(a.lay.ctx + q_slot * KC + c0 + 4 * tid), a.lay.ctx_cap, tag, s.x, s.y, s.z, s.w);
+        bt_store4<REP>(rs, par + (unsigned)a.lay.ctx + bt_word(c0 + 4 * tid, q_slot), a.lay.ctx_cap, tag, s.x, s.y, s.z, s.w);
       } else if (dg == 0 && tid < CQ + (KC - NQ * MEMW) / 4) {
         // the padding columns of the exchanged vector
-        bt_store4<REP>(rs, par + (unsigned)(a.lay.ctx + q_slot * KC + NQ * MEMW + 4 * (tid - CQ)), a.lay.ctx_cap, tag, 0.0f, 0.0f, 0.0f, 0.0f);
+        bt_store4<REP>(rs, par + (unsigned)a.lay.ctx + bt_word(NQ * MEMW + 4 * (tid - CQ), q_slot), a.lay.ctx_cap, tag, 0.0f, 0.0f, 0.0f, 0.0f);
       }
       BT_STAMP(8);
     }
@@ -932,7 +937,7 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
         const f32x4 bias = *reinterpret_cast<const f32x4*>(lds + L_BIAS + 16 + 4 * kq_f);
         const float hv = bt_lstm_cell(pre, bias, c_d);
         const int hu = j * 4 + kq;
-        bt_publish_units<REP>(rs, par + (unsigned)(a.lay.dh + utt * KH + j * 4), a.lay.dh_cap, tag, hu < Rd ? hv : 0.0f, lane);
+        bt_publish_units<REP>(rs, par + (unsigned)a.lay.dh + bt_word(j * 4, utt), a.lay.dh_cap, tag, hu < Rd ? hv : 0.0f, lane);
       }
       BT_STAMP(11);
       BT_SB();
@@ -1014,7 +1019,7 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
                 v = ((keep_l1 >> (8 * r)) & 0xffu) ? v * 2.0f : 0.0f;
                 hv1[r] = row < P ? v : 0.0f;
               }
-              bt_store4<REP>(rs, par_n + (unsigned)(a.lay.h1 + utt * KP + j * RP + 4 * kq), a.lay.h1_cap, tag_n, hv1[0], hv1[1], hv1[2], hv1[3]);
+              bt_store4<REP>(rs, par_n + (unsigned)a.lay.h1 + bt_word(j * RP + 4 * kq, utt), a.lay.h1_cap, tag_n, hv1[0], hv1[1], hv1[2], hv1[3]);
               keep_l2 = keep_next;
             }
           } else {
@@ -1183,9 +1188,17 @@ void taco_decoder_batch_dump_stamps(int n_frames) {
       acc[0] += (double)(nx[0] - prev) * 0.01;
     }
     if (cnt < 1) continue;
-    fprintf(stderr, "[bt stamps] workgroup %s, mean over %d frames (us):\n", wgn[wg], cnt);
+    // when each point is reached on the common clock: mean offset from the first stamped workgroup's frame top
+    double at[BT_STAMP_POINTS] = {0};
+    for (int t = 40; t + 1 < nfr; ++t) {
+      const unsigned long long* r = &st[((size_t)wg * BT_STAMP_FRAMES + t) * BT_STAMP_POINTS];
+      const unsigned long long base = st[((size_t)0 * BT_STAMP_FRAMES + t) * BT_STAMP_POINTS];
+      for (int k = 0; k < 15; ++k)
+        if (r[k] != 0) at[k] += ((double)r[k] - (double)base) * 0.01;
+    }
+    fprintf(stderr, "[bt stamps] workgroup %s, mean over %d frames (us; in brackets: reached at, from the P group's frame top):\n", wgn[wg], cnt);
     double tot = 0;
-    for (int k = 1; k < 15; ++k) if (acc[k] > 0) { fprintf(stderr, "  %-44s %7.2f\n", names[k], acc[k] / cnt); tot += acc[k] / cnt; }
+    for (int k = 1; k < 15; ++k) if (acc[k] > 0) { fprintf(stderr, "  %-44s %7.2f   [%6.2f]\n", names[k], acc[k] / cnt, at[k] / cnt); tot += acc[k] / cnt; }
     fprintf(stderr, "  %-44s %7.2f\n  total %7.2f\n", names[0], acc[0] / cnt, tot + acc[0] / cnt);
   }
 }

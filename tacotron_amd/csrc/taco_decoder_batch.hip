@@ -84,6 +84,17 @@ constexpr int QT = (TIN / 16 + NW - 1) / NW;   // tiles of 16 positions per wave
 constexpr int QR = 16 / NW;            // query rows per wave (4)
 constexpr int LOC_KSTEPS = 16;
 constexpr int RP = TACO_BT_ROWS;       // rows per P / M workgroup (one MFMA tile)
+// Who may wait: a vector that only some workgroups need at once is fetched later by the others (they have the time),
+// so that the L2 serves the ones in a hurry first.  In nap units (four = one s_sleep of 64 clocks).
+#ifndef TACO_BT_LAG_AH
+#define TACO_BT_LAG_AH 0
+#endif
+#ifndef TACO_BT_LAG_DH
+#define TACO_BT_LAG_DH 0
+#endif
+#ifndef TACO_BT_LOC_FIRST
+#define TACO_BT_LOC_FIRST 0
+#endif
 constexpr int W1_KSTEPS = (TACO_MAX_MEL + 3) / 4;    // 20
 static_assert(2 * TACO_MAX_K <= 4 * LOC_KSTEPS, "location taps fit 16 steps of 4");
 static_assert(QR == 4 && QT % 2 == 0 && CPG * CQ <= NT && MEMW % 4 == 0 && NQ * MEMW >= 544, "Q thread maps");
@@ -460,7 +471,7 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
   auto fill_slot = [&]() {
     len = a.lens ? min(a.lens[q_b], a.T_in) : a.T_in;
     len16 = (len + 15) & ~15;
-    pe_n = max(0, min(4, (len16 / 2 - (tid & 31) + 31) / 32));
+    pe_n = max(0, min(2, (len16 / 4 - (tid & 31) + 31) / 32));      // 16-byte loads (4 positions each) of my group: l, l + 32
     pm_lane = a.pm + (size_t)q_b * a.T_in * A + q_base + 4 * kq;
     const float* mem_b = a.memory + (size_t)q_b * a.T_in * M;
     _Pragma("unroll 1") for (int e = tid; e < len * MEMW; e += NT) {
@@ -529,7 +540,7 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
   };
   // Q: partial energies are gathered by thread (group tid >> 5, l = tid & 31): pairs of granules l, l + 32, l + 64, l + 96
   // of that group's positions
-  const unsigned pe_src0 = (unsigned)(a.lay.pe + 2 * ((q_slot * NQ + (tid >> 5)) * TIN + 2 * (tid & 31)));   // word index
+  const unsigned pe_src0 = (unsigned)(a.lay.pe + (q_slot * NQ + (tid >> 5)) * TIN + 4 * (tid & 31));   // word index
 
   f32x4 acc_a = {0.0f, 0.0f, 0.0f, 0.0f};     // attention-LSTM partial over [context ; hidden] of the previous frame
   f32x4 acc_dn = {0.0f, 0.0f, 0.0f, 0.0f};    // decoder-LSTM partial over the previous decoder hidden state
@@ -557,7 +568,6 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
     const unsigned tag = (((unsigned)t >> 1) & 1u) + 1u;                   // generation of this frame's words
     const unsigned par = (unsigned)(t & 1) * (unsigned)a.lay.per_parity;   // word offset of this frame's parity block
     uint32_t* gw = a.words + par;
-    taco_granule* g_pe = reinterpret_cast<taco_granule*>(gw + a.lay.pe);
     const int lane_f = BT_OPQ(lane);            // see BT_OPQ: addresses derived from these are recomputed every frame
     const int tid_f = lane_f + 64 * wave;
     const int utt_f = lane_f & 15, kq_f = lane_f >> 4;
@@ -754,7 +764,13 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
             for (int r = 0; r < 4; ++r) e = fmaf(vq[r], taco_tanh(q4[r] + u4[r]), e);
             e += __shfl_xor(e, 16, 64);
             e += __shfl_xor(e, 32, 64);
-            if (kq_f == 0) taco_publish(g_pe + (q_slot * NQ + dg) * TIN, s, ep, s < len ? e : 0.0f);
+            // four neighbouring positions meet in the first lane of their quad: one 16-byte store of tagged words
+            e = s < len ? e : 0.0f;
+            const float e1 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(e), 0x55, 0xf, 0xf, true));
+            const float e2 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(e), 0xaa, 0xf, 0xf, true));
+            const float e3 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(e), 0xff, 0xf, 0xf, true));
+            if (kq_f == 0 && (utt_f & 3) == 0)
+              bt_store4<1>(rs, par + (unsigned)(a.lay.pe + (q_slot * NQ + dg) * TIN + s), 0, tag, e, e1, e2, e3);
           }
         }
       }
@@ -768,8 +784,18 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
     {
       u32x4 vah[NL_H];
       f32x4 acc_d2 = {0.0f, 0.0f, 0.0f, 0.0f}, acc_an2 = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (!is_q) taco_nap(TACO_BT_LAG_AH);
       bt_nap_begin(nap_ah, wctx);
-      bt_issue<NL_H>(rs, par + w_lane_ah, vah);
+      if (is_q) {
+        // a Q workgroup has the softmax ahead of it and everybody waiting for its context: it takes half of the vector
+        // here - about what the partial energies take to travel - and the other half while its context travels
+#pragma unroll
+        for (int i = 0; i < NL_H / 2; ++i) vah[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (par + w_lane_ah + 256u * i) * 4u, 0, 16);
+#pragma unroll
+        for (int i = NL_H / 2; i < NL_H; ++i) vah[i] = u32x4{tag, tag, tag, tag};
+      } else {
+        bt_issue<NL_H>(rs, par + w_lane_ah, vah);
+      }
       BT_SB();
 #define BT_AH_BURST(c)                                                                             \
   bt_check<NL_H, BURST * (c), BURST>(rs, par + w_lane_ah, tag, vah, wctx, 0x600u);                  \
@@ -780,7 +806,8 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
     BT_MFMA4(wa_h, i, vah[i], acc_an, acc_an2)                                                     \
   }                                                                                                \
   BT_SB();
-      BT_AH_BURST(0) BT_AH_BURST(1) BT_AH_BURST(2) BT_AH_BURST(3)
+      BT_AH_BURST(0) BT_AH_BURST(1)
+      if (!is_q) { BT_AH_BURST(2) BT_AH_BURST(3) }
 #undef BT_AH_BURST
       acc_d += acc_d2;
       acc_an += acc_an2;
@@ -790,20 +817,21 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
     // ============ Q: energies of my utterance, softmax, my columns of the context ============
     if (is_q) {
       {
-        // partial energies: 8-byte granules, two per 16-byte load
-        u32x4 v[4];
+        // partial energies of my utterance's 8 workgroups: thread (group tid >> 5, l = tid & 31) takes positions
+        // 4 l .. 4 l + 3 and 4 (l + 32) .. of that group
+        u32x4 v[2];
         const unsigned src = par + pe_src0;
-        const int pd = BT_OPQ(LQ_XPE + (tid_f >> 5) * TIN + 2 * (tid_f & 31));
+        const int pd = BT_OPQ(LQ_XPE + (tid_f >> 5) * TIN + 4 * (tid_f & 31));
         unsigned spins = 0;
         bt_nap_begin(nap_pe, wctx);
         for (;;) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (src + 128u * i) * 4u, 0, 16);
+          for (int i = 0; i < 2; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (src + 128u * i) * 4u, 0, 16);
           unsigned bad = 0;
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (i < pe_n) bad |= (v[i].y ^ ep) | (v[i].w ^ ep);
-          if (__all(bad == 0u) || wctx.failed) break;
+          for (int i = 0; i < 2; ++i)
+            if (i < pe_n) bad |= (v[i].x ^ tag) | (v[i].y ^ tag) | (v[i].z ^ tag) | (v[i].w ^ tag);
+          if (__all((bad & 3u) == 0u) || wctx.failed) break;
           wctx.spun = 1;
           __builtin_amdgcn_s_sleep(TACO_POLL_SLEEP);
           if ((++spins & 255u) == 0u) {
@@ -819,8 +847,8 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
         }
         nap_pe = taco_nap_adjust(nap_pe, wctx.spun);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (i < pe_n) *reinterpret_cast<float2*>(lds + pd + 64 * i) = make_float2(__uint_as_float(v[i].x), __uint_as_float(v[i].z));     // {value, epoch} granules: exact values
+        for (int i = 0; i < 2; ++i)
+          if (i < pe_n) *reinterpret_cast<float4*>(lds + pd + 128 * i) = make_float4(BT_F(v[i].x), BT_F(v[i].y), BT_F(v[i].z), BT_F(v[i].w));
       }
       taco_lds_barrier();
       BT_STAMP(7);
@@ -908,13 +936,38 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
     f32x4 acc_r2 = {0.0f, 0.0f, 0.0f, 0.0f};
     {
       u32x4 vc[NL_C];
-      float4 wc4[NL_C];
-#pragma unroll
-      for (int i = 0; i < NL_C; ++i) wc4[i] = ws_lane[(NL_P + i) * 64];   // my attention-LSTM rows' context columns (L2): used after the publish below
-      bt_nap_begin(nap_ctx, wctx);
-      bt_issue<NL_C>(rs, par + w_lane_c, vc);
-      BT_SB();
       f32x4 acc_d2 = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (is_q) {
+        // Q: the other half of the attention hidden state (see above); the context loads go out before its last products
+        u32x4 vah[NL_H / 2];
+        f32x4 acc_an2 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int i = 0; i < NL_H / 2; ++i) vah[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (par + w_lane_ah + 256u * (NL_H / 2 + i)) * 4u, 0, 16);
+        BT_SB();
+        bt_check<NL_H / 2, 0, BURST>(rs, par + w_lane_ah + 256u * (NL_H / 2), tag, vah, wctx, 0x680u);
+        BT_SB();
+#pragma unroll
+        for (int i = 0; i < BURST; ++i) {
+          BT_MFMA4(wd_a, NL_H / 2 + i, vah[i], acc_d, acc_d2)
+          BT_MFMA4(wa_h, NL_H / 2 + i, vah[i], acc_an, acc_an)
+        }
+        BT_SB();
+        bt_issue<NL_C>(rs, par + w_lane_c, vc);
+        BT_SB();
+        bt_check<NL_H / 2, BURST, BURST>(rs, par + w_lane_ah + 256u * (NL_H / 2), tag, vah, wctx, 0x680u);
+        BT_SB();
+#pragma unroll
+        for (int i = BURST; i < 2 * BURST; ++i) {
+          BT_MFMA4(wd_a, NL_H / 2 + i, vah[i], acc_d, acc_d2)
+          BT_MFMA4(wa_h, NL_H / 2 + i, vah[i], acc_an, acc_an)
+        }
+        BT_SB();
+        wctx.spun = 0;
+      } else {
+        bt_nap_begin(nap_ctx, wctx);
+        bt_issue<NL_C>(rs, par + w_lane_c, vc);
+      }
+      BT_SB();
       bt_check<NL_C, 0, 3>(rs, par + w_lane_c, tag, vc, wctx, 0x800u);
       nap_ctx = taco_nap_adjust(nap_ctx, wctx.spun);
       BT_STAMP(10);
@@ -941,6 +994,9 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
       }
       BT_STAMP(11);
       BT_SB();
+      float4 wc4[NL_C];
+#pragma unroll
+      for (int i = 0; i < NL_C; ++i) wc4[i] = ws_lane[(NL_P + i) * 64];   // my attention-LSTM rows' context columns (L2)
       // while the decoder hidden state travels: the context columns of the P / M rows ...
       if ((is_p && !forced) || is_m) {
         const float* crow = lds + BT_OPQ((is_p ? LP_WF : LM_W) + (KH / 4 + wave * 4 * NL_C) * 64 + lane_f);
@@ -966,6 +1022,8 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
     // ============ the decoder hidden state; P: next frame's layer-1 rows; M: the frame's output ============
     {
       u32x4 vdh[NL_H];
+      if (TACO_BT_LOC_FIRST && is_q) update_location_term(lane_f);
+      if (!is_p && !is_m) taco_nap(TACO_BT_LAG_DH);
       bt_nap_begin(nap_dh, wctx);
       bt_issue<NL_H>(rs, par + w_lane_dh, vdh);
       BT_SB();
@@ -1061,7 +1119,7 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
       }
     }
     // Q: next frame's location term, while the P group works on the next frame's prenet output
-    if (is_q) update_location_term(lane_f);
+    if (!TACO_BT_LOC_FIRST && is_q) update_location_term(lane_f);
     BT_STAMP(14);
   }
 
@@ -1127,7 +1185,7 @@ void taco_decoder_batch_fill_layout(taco_bat_layout* lay) {
   lay->ah = take(NB * KH, TACO_BT_REP, &lay->ah_cap);
   lay->ctx = take(NB * KC, TACO_BT_REP, &lay->ctx_cap);
   lay->dh = take(NB * KH, TACO_BT_REP, &lay->dh_cap);
-  lay->pe = take(2 * NB * NQ * TIN, 1, nullptr);          // 8-byte granules: two words each
+  lay->pe = take(NB * NQ * TIN, 1, nullptr);
   lay->stop = take(2 * NB, TACO_BT_REP, &lay->stop_cap);
   lay->per_parity = off;
 }

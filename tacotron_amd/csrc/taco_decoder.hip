@@ -164,8 +164,8 @@ constexpr int TACO_STAMP_FRAMES = 256, TACO_STAMP_POINTS = 12;
   } while (0)
 #define TACO_QALL(k)                                                                                    \
   do {                                                                                                  \
-    if (tid == 0 && is_q && t < TACO_STAMP_FRAMES)                                                      \
-      a.stamps[((size_t)(4 + (j - q_off)) * TACO_STAMP_FRAMES + t) * TACO_STAMP_POINTS + (k)] = wall_clock64(); \
+    if (tid == 0 && is_q && q_half == 0 && t < TACO_STAMP_FRAMES)                                       \
+      a.stamps[((size_t)(4 + q_grp) * TACO_STAMP_FRAMES + t) * TACO_STAMP_POINTS + (k)] = wall_clock64(); \
   } while (0)
 #define TACO_PSTAMP(k)                                                                                  \
   do {                                                                                                  \
@@ -270,6 +270,9 @@ __device__ __forceinline__ float lstm_cell_lanes(const float* gates_lds, const f
 // STD = true fixes the extents of the usual checkpoint geometry (prenet 256, both LSTMs 1024, attention
 // 128 / kernel 31, 80 mel channels, 256 workgroups) at compile time: fewer live scalars and no bounds
 // arithmetic in the frame loop.  STD = false takes every extent from the arguments.
+#ifndef TACO_Q_POS
+#define TACO_Q_POS 64          // positions per Q workgroup
+#endif
 template <bool STD, int NCTX>
 __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const DecArgs a) {
   constexpr int CH_A = TACO_NP + NCTX + TACO_NA;    // chunks per attention-LSTM row (6 or 7)
@@ -364,13 +367,24 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
   const int qd = (A + TACO_NQ_WG - 1) / TACO_NQ_WG;            // attention dimensions per Q workgroup (<= QD)
   const int n_q_wg = (A + qd - 1) / qd;
   const int n_m_wg = (NMEL + 1 + TACO_MEL_ROWS_WG - 1) / TACO_MEL_ROWS_WG;
-  const int q_off = n_p_wg, m_off = n_p_wg + n_q_wg;
+  // The Q group is multiplied by the input length: one workgroup per group of dimensions AND per 64 positions
+  // (location term, energy terms, partial sums of those positions).  That stage is the frame's longest piece of work
+  // and its length goes with the positions a workgroup has: with 64 a wave's energy loop is one pass and its location
+  // tiles one round.  (Measured against one workgroup per group of dimensions: 7.62 -> 7.44 us per frame at 102
+  // positions, 8.36 -> 7.68 at 200, 10.6 -> 8.5 at 300, 12.9 -> 8.55 at 512; below 65 positions nothing changes.)
+  const int Q_SPLIT = (len + TACO_Q_POS - 1) / TACO_Q_POS;
+  const int q_off = n_p_wg, m_off = n_p_wg + n_q_wg * Q_SPLIT;
   const bool is_p = j < n_p_wg;
   const bool is_q = j >= q_off && j < m_off;
+  const int q_grp = is_q ? (j - q_off) % n_q_wg : 0;           // my group of dimensions
+  const int q_half = is_q ? (j - q_off) / n_q_wg : 0;          // my part of the positions
+  const int q_lo = min(q_half * TACO_Q_POS, len4);                    // my positions [q_lo, q_hi); [q_lo, q_hi4) with the partials' padding
+  const int q_hi4 = min(q_lo + TACO_Q_POS, len4);
+  const int q_hi = min(q_hi4, len);
   const bool is_m = j >= m_off && j < m_off + n_m_wg;
   const int p_row = is_p ? j * TACO_P_ROWS_WG + wave : P;                          // >= P: none
   const bool own_p = p_row < P;
-  const int q_base = is_q ? (j - q_off) * qd : 0;                                  // my first attention dimension
+  const int q_base = is_q ? q_grp * qd : 0;                                        // my first attention dimension
   const int q_cnt = is_q ? min(qd, A - q_base) : 0;                                // my dimensions
   const int m_row = (is_m && wave >= 1 && wave <= TACO_MEL_ROWS_WG) ? (j - m_off) * TACO_MEL_ROWS_WG + (wave - 1)
                                                                     : NMEL + 1;    // row n_mel is the stop-token row
@@ -461,7 +475,7 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
     if (NCTX == 1) {
       // every position's processed memory is in LDS (the one-chunk instance runs inputs of up to LQ_PM_POS positions)
       if (pass != 0) return;
-      _Pragma("unroll 1") for (int s0 = wave * 16; s0 < len; s0 += NW * 16) {
+      _Pragma("unroll 1") for (int s0 = q_lo + wave * 16; s0 < q_hi; s0 += NW * 16) {
         const taco_f32x4 acc = tile_products(s0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -473,7 +487,7 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
       // processed memory from global memory (L2), asked for before the products so that the round trip runs
       // beside them.  (Keeping the first LQ_PM_POS positions in LDS and fetching only the rest, ahead of the
       // other tiles, cost registers this instance does not have: it spilled and came out slower.)
-      _Pragma("unroll 1") for (int s0 = (wave + NW * pass) * 16; s0 < len; s0 += 2 * NW * 16) {
+      _Pragma("unroll 1") for (int s0 = q_lo + (wave + NW * pass) * 16; s0 < q_hi; s0 += 2 * NW * 16) {
         const int s = s0 + col;
         float pmv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -612,7 +626,7 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
       vv[0] = lds[LQ_V + wave * 2];           // rows beyond my dimensions: zero row, v = 0, finite U
       vv[1] = lds[LQ_V + wave * 2 + 1];
       TACO_QSTAMP(1);
-      _Pragma("unroll 2") for (int s = lane; s < len; s += 64) {
+      _Pragma("unroll 2") for (int s = q_lo + lane; s < q_hi; s += 64) {
         const float e0 = vv[0] * taco_tanh(qv[0] + lds[LQ_U + (wave * 2 + 0) * TACO_MAX_TIN + s]);
         const float e1 = vv[1] * taco_tanh(qv[1] + lds[LQ_U + (wave * 2 + 1) * TACO_MAX_TIN + s]);
         lds[LQ_PE8 + wave * TACO_MAX_TIN + s] = e0 + e1;
@@ -621,8 +635,8 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
       taco_lds_barrier();
       TACO_QSTAMP(3);
       {
-        const int grp = j - q_off;
-        _Pragma("unroll 1") for (int s = tid; s < len4; s += NT) {
+        const int grp = q_grp;
+        _Pragma("unroll 1") for (int s = q_lo + tid; s < q_hi4; s += NT) {
           float e = 0.0f;
           if (s < len) {
 #pragma unroll
@@ -807,7 +821,7 @@ int taco_decoder_check_dims(const taco_dims& d, int n_wg) {
   if (d.K > TACO_MAX_K || (d.K & 1) == 0) TACO_FAIL(TACO_EINVAL, "attention_location_kernel_size %d must be odd and <= %d", d.K, TACO_MAX_K);
   if (d.n_mel > TACO_MAX_MEL) TACO_FAIL(TACO_EINVAL, "n_mel_channels %d exceeds %d", d.n_mel, TACO_MAX_MEL);
   const int qd = (d.A + TACO_NQ_WG - 1) / TACO_NQ_WG;
-  const int groups = (d.P + TACO_P_ROWS_WG - 1) / TACO_P_ROWS_WG + (d.A + qd - 1) / qd +
+  const int groups = (d.P + TACO_P_ROWS_WG - 1) / TACO_P_ROWS_WG + ((TACO_MAX_TIN + TACO_Q_POS - 1) / TACO_Q_POS) * ((d.A + qd - 1) / qd) +      // (the Q group at the longest input)
                      (d.n_mel + 1 + TACO_MEL_ROWS_WG - 1) / TACO_MEL_ROWS_WG;
   if (groups > n_wg) TACO_FAIL(TACO_EINVAL, "the decoder's producer groups need %d workgroups, the device has %d CUs", groups, n_wg);
   return TACO_OK;

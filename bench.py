@@ -160,7 +160,7 @@ def flops_per_frame(d, T_in):
 
 def batch64_record(model, ckpt, device, frames=600, reps=3):
   """BASELINE configs[2]: 64 synthetic lines (40..160 symbols, generator seed 2024, longest first) in one padded batch,
-  every line run to `frames` decoder steps: encode + lockstep decoder (16 utterances per persistent launch) + postnet."""
+  every line run to `frames` decoder steps: encode + lockstep decoder (one persistent launch, 16 utterances in flight) + postnet."""
   from tacotron_amd import scenarios
   from tacotron_amd.masks import prenet_keep_masks
   lens = sorted(np.random.RandomState(2024).randint(40, 161, size=64).tolist(), reverse=True)
@@ -198,19 +198,19 @@ def batch64_record(model, ckpt, device, frames=600, reps=3):
                 "valu_issue_fraction": prof.get("SQ_ACTIVE_INST_VALU_per_WAVE_CYCLE"),
                 "scalar_issue_fraction": prof.get("SQ_ACTIVE_INST_SCA_per_WAVE_CYCLE")}
     if prof.get("hbm_bytes_per_lockstep_frame"):
-      traffic = int(prof["hbm_bytes_per_lockstep_frame"]) * frames
+      traffic = int(prof["hbm_bytes_per_lockstep_frame"]) * (64 * frames // 16)
   return {"workload": f"64 lines of {min(lens)}..{max(lens)} symbols in one padded batch, {frames} frames each, lockstep decoder "
-                      "(16 utterances per persistent launch)",
+                      "(one persistent launch, 16 utterances in flight)",
           "value": round(total / dt, 1), "unit": "mel frames/s", "ms_per_batch": round(dt * 1e3, 3),
           "decoder_us_per_lockstep_frame": round(dec_s / (4 * frames) * 1e6, 3),
           "decoder_us_per_utterance_frame": round(dec_s / total * 1e6, 4),
           "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                        "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
                        "traffic_source": counters and counters["source"], "counters": counters, "kernel": "taco_decoder_batch_kernel",
-                       "flops_per_launch": int(flops / 4), "kernel_ms_per_launch": round(dec_s / 4 * 1e3, 4),
-                       "note": "algorithmic FLOPs (2 x weights touched + attention, per utterance and frame) of the four launches "
-                               "of a batch of 64 / their device time (HIP events on the launch stream); exact-f32 matrix-core "
-                               "products run at the f32 vector rate, 1/16 of the bf16 rate"}}
+                       "flops_per_launch": int(flops), "kernel_ms_per_launch": round(dec_s * 1e3, 4),
+                       "note": "algorithmic FLOPs (2 x weights touched + attention, per utterance and frame) of the one launch that "
+                               "decodes the batch of 64 (16 utterances in flight, slots refilled) / its device time (HIP events on "
+                               "the launch stream); exact-f32 matrix-core products run at the f32 vector rate, 1/16 of the bf16 rate"}}
 
 
 def lines_workload(model, ckpt, device, world, rank, lines_per_gpu, frames, batch_size):
@@ -241,7 +241,7 @@ def lines_workload(model, ckpt, device, world, rank, lines_per_gpu, frames, batc
 
   desc = (f"{n_lines} synthetic lines (T_in ~ U{{20..200}}, seed 2024), {frames} decoder frames each (stop disabled), "
           f"partitioned longest-processing-time-first over {world} rank(s), padded batches of {batch_size} "
-          "(lockstep decoder, 16 utterances per persistent launch), encoder + decoder + postnet")
+          "(lockstep decoder, one persistent launch per batch, 16 utterances in flight), encoder + decoder + postnet")
   return step, len(mine) * frames, n_lines * frames, desc
 
 

@@ -6,7 +6,7 @@
 set -e
 tag=${1:?tag}
 root=$(pwd)
-out=$root/gpurun_out/prof_$tag
+out=$root/gpurun_out/prof_${tag}_lockstep
 mkdir -p "$out"
 export TMPDIR=/tmp
 timeout -k 10 200 python3 scripts/batch_once.py 64 600 3 > "$out/batch64.txt" 2> "$out/batch64.err"

@@ -3,8 +3,8 @@
 
   <tag>_lockstep_batch64.txt        the untraced throughput line
   <tag>_lockstep_kernel_stats.csv   per-kernel calls / total / average from the kernel trace
-  <tag>_lockstep_pmc.json           counters of taco_decoder_batch_kernel per dispatch (one dispatch = 16 utterances
-                                    x 600 frames) and what follows from them: matrix-core busy share, issue
+  <tag>_lockstep_pmc.json           counters of taco_decoder_batch_kernel per dispatch (one dispatch = the batch of 64:
+                                    2400 lockstep frames) and what follows from them: matrix-core busy share, issue
                                     fractions, HBM bytes per lockstep frame
 """
 import csv
@@ -16,9 +16,9 @@ from pathlib import Path
 
 root = Path(__file__).resolve().parent.parent
 tag = sys.argv[1]
-src = root / "gpurun_out" / f"prof_{tag}"
+src = root / "gpurun_out" / f"prof_{tag}_lockstep"
 dst = root / "profiles"
-FRAMES = 600
+FRAMES = 64 * 600 // 16     # lockstep frames of the one dispatch that decodes the batch: 64 utterances x 600 frames, 16 in flight
 KERNEL = "taco_decoder_batch_kernel"
 SIMDS = 256 * 4
 
@@ -75,7 +75,7 @@ if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
   d["hbm_bytes_per_lockstep_frame"] = int(round((2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 / FRAMES))
   d["traffic_correction"] = "FETCH_SIZE x2 (gfx950 reports half), WRITE_SIZE as reported, KiB units, separate passes"
 (dst / f"{tag}_lockstep_pmc.json").write_text(json.dumps({
-  "kernel": KERNEL, "workload": "64 lines of 40..160 symbols, 600 frames each: 4 dispatches of 16 utterances",
+  "kernel": KERNEL, "workload": "64 lines of 40..160 symbols, 600 frames each: one dispatch, 16 utterances in flight, slots refilled",
   "lockstep_frames_per_dispatch": FRAMES, "kernel_avg_ns": kernel_ns,
   "per_dispatch": {k: round(v, 1) for k, v in sorted(c.items())}, "derived": d,
   "command": "rocprofv3 --pmc <one block-limited set per pass> -- python3 scripts/batch_once.py 64 600 1 (scripts/profile_lockstep.sh)",

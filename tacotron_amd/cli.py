@@ -183,14 +183,24 @@ def synthesize_plan(synth, plan: Sequence[PlannedLine], speaker: Optional[str], 
         i, future = pending.popleft()
         out[i] = future.result()
 
-    with concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="taco-write") as writer:
-      for group_idx in sharding.batches(indices, batch_size):
+    groups = list(sharding.batches(indices, batch_size))
+    with concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="taco-write") as writer, \
+         concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="taco-prep") as prep:
+      # In batch mode the next batch's symbols are mapped to ids on a second thread while the GPU decodes the
+      # current one (the library call releases the interpreter lock for as long as the decoder runs).
+      ahead = None
+      if batch_size > 1 and groups and hasattr(synth, "prepare_batch"):
+        ahead = prep.submit(synth.prepare_batch, [plan[i].symbols for i in groups[0]], speaker)
+      for g, group_idx in enumerate(groups):
         if batch_size == 1:
           results = [synth.infer(symbols=plan[group_idx[0]].symbols, speaker=speaker, include_stats=include_stats,
                                  max_decoder_steps=max_decoder_steps, seed=seed)]
         else:
-          results = synth.infer_batch([plan[i].symbols for i in group_idx], speaker=speaker,
-                                      max_decoder_steps=max_decoder_steps, seed=seed, include_stats=include_stats)
+          prepared = ahead.result() if ahead is not None else None
+          if ahead is not None:
+            ahead = prep.submit(synth.prepare_batch, [plan[i].symbols for i in groups[g + 1]], speaker) if g + 1 < len(groups) else None
+          results = synth.infer_batch([plan[i].symbols for i in group_idx], speaker=speaker, max_decoder_steps=max_decoder_steps,
+                                      seed=seed, include_stats=include_stats, **({} if prepared is None else {"prepared": prepared}))
         for i, res in zip(group_idx, results):
           pending.append((i, writer.submit(_write_line, plan[i], res, include_stats)))
         settle(WRITE_BEHIND)

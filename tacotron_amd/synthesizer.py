@@ -197,18 +197,26 @@ class Synthesizer:
       res.mel_outputs, res.gate_outputs, res.alignments = to_np(mel), to_np(gate), to_np(align)
     return res
 
+  def prepare_batch(self, lines: Sequence[Sequence[str]], speaker: Optional[str]) -> List[_Prepared]:
+    """The host-side half of ``infer_batch`` (symbols -> ids, unknown symbols dropped): pure Python, so a caller may
+    run it for the next batch on another thread while the GPU decodes the current one."""
+    preps = [self._prepare(line, speaker) for line in lines]
+    if preps and min(len(p.ids["symbols"]) for p in preps) < 1:
+      raise ValueError("a line has no mappable symbol")
+    return preps
+
   def infer_batch(self, lines: Sequence[Sequence[str]], speaker: Optional[str], max_decoder_steps: int = 3000,
-                  seed: int = 0, include_stats: bool = False, keep_on_device: bool = False) -> List[InferenceResult]:
+                  seed: int = 0, include_stats: bool = False, keep_on_device: bool = False,
+                  prepared: Optional[List[_Prepared]] = None) -> List[InferenceResult]:
     """Synthesizes several lines in one padded batch; every line gets the result ``infer`` would
     give it (same seed for each, as the CLI reuses one seed for all lines:
     src/tacotron_cli/inference.py:137-141).  ``inference_duration_s`` is the batch time / lines.
-    ``keep_on_device``: as in ``infer``; each line's arrays are views into the batch's device tensors."""
+    ``keep_on_device``: as in ``infer``; each line's arrays are views into the batch's device tensors.
+    ``prepared``: what ``prepare_batch(lines, speaker)`` returned, if the caller ran it ahead of time."""
     if len(lines) == 0:
       return []
-    preps = [self._prepare(line, speaker) for line in lines]
+    preps = prepared if prepared is not None else self.prepare_batch(lines, speaker)
     lens = [len(p.ids["symbols"]) for p in preps]
-    if min(lens) < 1:
-      raise ValueError("a line has no mappable symbol")
     T = max(lens)
     init_global_seeds(seed)
 
@@ -233,16 +241,23 @@ class Synthesizer:
     seconds = (time.perf_counter() - start) / len(preps)
     n_frames = n_frames.cpu().tolist()
     reached = reached.cpu().tolist()
-    def hand(t):
-      return t if keep_on_device else t.cpu().numpy()
+    if not keep_on_device:
+      # one copy per array for the whole batch (up to its longest utterance), sliced per line on the host
+      n_max = max(n_frames)
+      post = post[:, :, :n_max].cpu().numpy()
+      if include_stats:
+        mel, gate, align = mel[:, :, :n_max].cpu().numpy(), gate[:, :n_max].cpu().numpy(), align[:, :n_max].cpu().numpy()
+
+    def own(a):
+      return a if keep_on_device else np.ascontiguousarray(a)
 
     out = []
     for b, p in enumerate(preps):
       n = n_frames[b]
-      res = self._result(p, hand(post[b, :, :n]), bool(reached[b]), seconds)
+      res = self._result(p, own(post[b, :, :n]), bool(reached[b]), seconds)
       if include_stats:
-        res.mel_outputs = hand(mel[b, :, :n])
-        res.gate_outputs = hand(gate[b, :n].unsqueeze(-1))
-        res.alignments = hand(align[b, :n, :lens[b]])
+        res.mel_outputs = own(mel[b, :, :n])
+        res.gate_outputs = own(gate[b, :n, None] if not keep_on_device else gate[b, :n].unsqueeze(-1))
+        res.alignments = own(align[b, :n, :lens[b]])
       out.append(res)
     return out

@@ -337,13 +337,11 @@ def main():
       "note": "one GPU runs workload b1 by default (batch-1 latency, BASELINE configs[1]); `--workload lines` gives the one-GPU "
               "figure of this workload",
     }
-    if world == 1:
-      out["batch64"] = batch64_record(model, ckpt, device)
-      out["roofline"] = out["batch64"]["roofline"]
-      out["cpu_baseline"] = None
-    else:
-      out["roofline"] = None
-      out["cpu_baseline"] = None
+    # the dominant kernel's roofline: measured on this rank's GPU outside the timed region (every rank does the same
+    # work, rank 0's figures are printed); the CPU baseline belongs to the one-GPU run of workload b1
+    out["batch64"] = batch64_record(model, ckpt, device)
+    out["roofline"] = out["batch64"]["roofline"]
+    out["cpu_baseline"] = None
     if rank == 0:
       print(json.dumps(out), flush=True)
     if dist is not None:

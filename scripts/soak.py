@@ -39,5 +39,39 @@ for T_in in (1, 30, 102, 256, 300, 512):
       print(f"T_in={T_in} launch {i}: output differs from the first launch", flush=True)
   torch.cuda.synchronize()
   print(f"T_in={T_in}: {n} launches x {frames} frames identical={bad == 0} ({time.perf_counter() - t0:.1f} s)", flush=True)
+# the lockstep decoder: ragged batches with the stop test live (slots refill at different frames), every launch compared
+# bit for bit with the first of its kind; and the same lines in reverse order must give the same frames
+gate = __import__("json").load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "gate_bias.json")))["ljs"]
+ckpt = scenarios.checkpoint("ljs", gate)
+hp = get_hparams(ckpt)
+m = Tacotron2(hp, **abi.mapping_counts(ckpt, hp)); m.load_state_dict(ckpt["model_state"]); m.to("cuda:0")
+for B, steps in ((64, 400), (17, 150), (200, 250)):
+  lens = np.random.RandomState(B).randint(3, 209, size=B).tolist()
+  ids = scenarios.random_ids(ckpt, lens, seed=B)
+  for b in range(B):
+    ids["speakers"][b, :] = ids["speakers"][b, 0]
+  chans = [d(ids[k]) for k in ("symbols", "stresses", "tones", "durations") if ids[k] is not None]
+  ln = d(np.array(lens, np.int32))
+  mem, pm = m.encode(chans, d(ids["speakers"]), ln)
+  mk = prenet_keep_masks(7, steps, m.dims.P).to("cuda:0")
+  flip = torch.arange(B - 1, -1, -1, device="cuda:0")
+  mem_r, pm_r, ln_r = mem[flip].contiguous(), pm[flip].contiguous(), ln[flip].contiguous()
+  first = None
+  t0 = time.perf_counter()
+  reps = max(4, n // 6)
+  for i in range(reps):
+    if i % 2 == 0:
+      mel, gt, align, nf, reached = m.decode(mem, pm, ln, mk, steps)
+    else:
+      mel, gt, align, nf, reached = (x[flip] for x in m.decode(mem_r, pm_r, ln_r, mk, steps))
+    if first is None:
+      first = (mel.clone(), gt.clone(), align.clone(), nf.clone())
+      assert bool(torch.isfinite(mel).all()) and len(set(nf.cpu().tolist())) > 3
+    elif not (torch.equal(mel, first[0]) and torch.equal(gt, first[1]) and torch.equal(align, first[2]) and torch.equal(nf, first[3])):
+      bad += 1
+      print(f"lockstep B={B} launch {i}: output differs from the first launch", flush=True)
+  torch.cuda.synchronize()
+  print(f"lockstep B={B}: {reps} launches (forwards / backwards), {int(first[3].sum())} frames each, identical={bad == 0} "
+        f"({time.perf_counter() - t0:.1f} s)", flush=True)
 print("soak", "FAILED" if bad else "ok")
 sys.exit(1 if bad else 0)

@@ -165,7 +165,7 @@ struct BatArgs {
 };
 
 #ifdef TACO_BT_STAMPS
-constexpr int BT_STAMP_FRAMES = 256, BT_STAMP_POINTS = 16;
+constexpr int BT_STAMP_FRAMES = 256, BT_STAMP_POINTS = 24;
 #define BT_STAMP(k)                                                                                         \
   do {                                                                                                      \
     if (tid == 0 && stamp_wg >= 0 && t < BT_STAMP_FRAMES)                                                   \
@@ -750,6 +750,7 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
         if (lane == 0) *reinterpret_cast<float4*>(lds + LQ_Q + QR * wave) = make_float4(s0, s1, s2, s3);
       }
       taco_lds_barrier();
+      BT_STAMP(16);
       {
         const float* uq = lds + BT_OPQ(LQ_Q + 4 * kq_f);       // query values; the U rows follow within immediate reach
         const f32x4 q4 = *reinterpret_cast<const f32x4*>(uq);
@@ -870,6 +871,7 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
           mx = fmaxf(fmaxf(m0.x, m0.y), fmaxf(m0.z, m0.w));
         }
         const float x = tid < len ? taco_exp(e - mx) : 0.0f;
+        BT_STAMP(17);
         const float part = taco_wave_sum(x);
         if (lane == 0) sred[wave] = part;
         taco_lds_barrier();
@@ -884,6 +886,7 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
         if (dg == 0 && a.align && ((alive >> q_slot) & 1u)) a.align[((size_t)q_b * a.T_cap + (t - q_t0)) * a.T_in + tid] = w_own;
       }
       taco_lds_barrier();
+      BT_STAMP(18);
       // context columns: thread (column quad cg, position group pg) sums its positions for 4 columns; the 15 groups
       // meet in LDS (the partial-energy area is free again)
       {
@@ -913,19 +916,30 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
         }
       }
       taco_lds_barrier();
-      if (tid < CQ) {
-        // thread = column quad: the 15 groups' partial sums of its 4 columns, one 16-byte store (columns at or beyond M are zeros)
+      BT_STAMP(19);
+      if (tid < 4 * CQ) {
+        // four threads per column quad: each adds up to four of the 15 groups' partial sums, the four meet inside their
+        // quad of lanes, the first stores 16 bytes (columns at or beyond M are zeros)
+        const int cgq = tid_f >> 2, part = tid_f & 3;
         float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        const float* cp = lds + BT_OPQ(LQ_XPE + 4 * tid_f);
+        const float* cp = lds + BT_OPQ(LQ_XPE + 4 * cgq + part * MEMW);
 #pragma unroll
-        for (int pg = 0; pg < CPG; ++pg) {
-          const float4 v = *reinterpret_cast<const float4*>(cp + pg * MEMW);
-          s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        for (int i = 0; i < (CPG + 3) / 4; ++i) {
+          if (part + 4 * i < CPG) {
+            const float4 v = *reinterpret_cast<const float4*>(cp + 4 * i * MEMW);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+          }
         }
-        bt_store4<REP>(rs, par + (unsigned)a.lay.ctx + bt_word(c0 + 4 * tid, q_slot), a.lay.ctx_cap, tag, s.x, s.y, s.z, s.w);
-      } else if (dg == 0 && tid < CQ + (KC - NQ * MEMW) / 4) {
+        auto quad_sum = [](float v) {
+          v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xb1, 0xf, 0xf, true));      // lanes 1 0 3 2
+          v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4e, 0xf, 0xf, true));      // lanes 2 3 0 1
+          return v;
+        };
+        s.x = quad_sum(s.x); s.y = quad_sum(s.y); s.z = quad_sum(s.z); s.w = quad_sum(s.w);
+        if (part == 0) bt_store4<REP>(rs, par + (unsigned)a.lay.ctx + bt_word(c0 + 4 * cgq, q_slot), a.lay.ctx_cap, tag, s.x, s.y, s.z, s.w);
+      } else if (dg == 0 && tid < 4 * CQ + (KC - NQ * MEMW) / 4) {
         // the padding columns of the exchanged vector
-        bt_store4<REP>(rs, par + (unsigned)a.lay.ctx + bt_word(NQ * MEMW + 4 * (tid - CQ), q_slot), a.lay.ctx_cap, tag, 0.0f, 0.0f, 0.0f, 0.0f);
+        bt_store4<REP>(rs, par + (unsigned)a.lay.ctx + bt_word(NQ * MEMW + 4 * (tid - 4 * CQ), q_slot), a.lay.ctx_cap, tag, 0.0f, 0.0f, 0.0f, 0.0f);
       }
       BT_STAMP(8);
     }
@@ -1049,6 +1063,7 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
         BT_ROWS_BURST(0) BT_ROWS_BURST(1) BT_ROWS_BURST(2) BT_ROWS_BURST(3)
 #undef BT_ROWS_BURST
         acc_r += acc_r2;
+        BT_STAMP(9);
         if (is_p && forced) {
           // teacher forcing: the plain layer-1 rows on the given frame (wave w takes k-steps 5w .. 5w + 4)
           constexpr int W1_PER_WAVE = (W1_KSTEPS + NW - 1) / NW;
@@ -1063,6 +1078,7 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
           }
         }
         const f32x4 sum = bt_reduce_tiles(lds, is_p ? LP_RED : LM_RED, acc_r, wave, lane_f);
+        BT_STAMP(15);
         if (wave == 0) {
           if (is_p) {
             {
@@ -1219,7 +1235,8 @@ int taco_decoder_batch_prepare(taco_handle h) {
 #ifdef TACO_BT_STAMPS
 #include <stdio.h>
 static unsigned long long* g_bt_stamps = nullptr;
-// Diagnostic build: mean time between consecutive stamp points of the last launch, per stamped workgroup.
+// Diagnostic build: when each stamp point of the last launch is reached, per stamped workgroup, on the common clock
+// (mean over the frames, measured from the first P workgroup's frame top), in the order in which they are reached.
 void taco_decoder_batch_dump_stamps(int n_frames) {
   if (!g_bt_stamps) return;
   const size_t n = (size_t)4 * BT_STAMP_FRAMES * BT_STAMP_POINTS;
@@ -1227,37 +1244,29 @@ void taco_decoder_batch_dump_stamps(int n_frames) {
   if (hipMemcpy(st.data(), g_bt_stamps, n * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
   const int nfr = n_frames < BT_STAMP_FRAMES ? n_frames : BT_STAMP_FRAMES;
   static const char* wgn[4] = {"P (0)", "M (first)", "Q (first)", "plain (last)"};
-  static const char* names[BT_STAMP_POINTS] = {"top: P layer 2 + publish p", "stop test", "p loaded", "att MFMA+reduce+cell+publish ah",
-      "Q: ah gathered", "Q: query+energies+publish pe", "ah loads + dec columns", "Q: pe gathered", "Q: softmax+ctx+publish",
-      "-", "ctx first burst loaded", "dec MFMA+reduce+cell+publish dh", "slack products + dh first burst", "P/M rows+epilogue",
-      "recurrent MFMAs (+ Q: location term)", ""};
+  static const char* names[BT_STAMP_POINTS] = {"frame top: P layer 2 done, p published", "stop test done", "p loaded", "att MFMA+reduce+cell, ah published",
+      "Q: ah of my utterance gathered", "Q: query+energies, pe published", "ah loads + products done", "Q: pe gathered", "Q: softmax+ctx, ctx published",
+      "P/M: all row products issued", "ctx first burst loaded", "dec MFMA+reduce+cell, dh published", "slack products done, dh first burst loaded",
+      "P/M: rows reduced, epilogue, h1 / frame published", "recurrent MFMAs (+ Q: location term) done", "P/M: tiles reduced",
+      "Q: query values in LDS", "Q: energies summed, exp done", "Q: weights normalised, in LDS", "Q: context partial sums in LDS", "", "", "", ""};
   for (int wg = 0; wg < 4; ++wg) {
-    double acc[BT_STAMP_POINTS] = {0};
-    int cnt = 0;
-    for (int t = 40; t + 1 < nfr; ++t, ++cnt) {
-      const unsigned long long* r = &st[((size_t)wg * BT_STAMP_FRAMES + t) * BT_STAMP_POINTS];
-      const unsigned long long* nx = &st[((size_t)wg * BT_STAMP_FRAMES + t + 1) * BT_STAMP_POINTS];
-      unsigned long long prev = r[0];
-      for (int k = 1; k < 15; ++k) {
-        if (r[k] == 0) continue;
-        acc[k] += (double)(r[k] - prev) * 0.01;
-        prev = r[k];
-      }
-      acc[0] += (double)(nx[0] - prev) * 0.01;
-    }
-    if (cnt < 1) continue;
-    // when each point is reached on the common clock: mean offset from the first stamped workgroup's frame top
     double at[BT_STAMP_POINTS] = {0};
+    int cnt[BT_STAMP_POINTS] = {0};
     for (int t = 40; t + 1 < nfr; ++t) {
       const unsigned long long* r = &st[((size_t)wg * BT_STAMP_FRAMES + t) * BT_STAMP_POINTS];
       const unsigned long long base = st[((size_t)0 * BT_STAMP_FRAMES + t) * BT_STAMP_POINTS];
-      for (int k = 0; k < 15; ++k)
-        if (r[k] != 0) at[k] += ((double)r[k] - (double)base) * 0.01;
+      for (int k = 0; k < BT_STAMP_POINTS; ++k)
+        if (r[k] != 0) { at[k] += ((double)r[k] - (double)base) * 0.01; ++cnt[k]; }
     }
-    fprintf(stderr, "[bt stamps] workgroup %s, mean over %d frames (us; in brackets: reached at, from the P group's frame top):\n", wgn[wg], cnt);
-    double tot = 0;
-    for (int k = 1; k < 15; ++k) if (acc[k] > 0) { fprintf(stderr, "  %-44s %7.2f   [%6.2f]\n", names[k], acc[k] / cnt, at[k] / cnt); tot += acc[k] / cnt; }
-    fprintf(stderr, "  %-44s %7.2f\n  total %7.2f\n", names[0], acc[0] / cnt, tot + acc[0] / cnt);
+    int order[BT_STAMP_POINTS], m = 0;
+    for (int k = 0; k < BT_STAMP_POINTS; ++k)
+      if (cnt[k] > 0) { at[k] /= cnt[k]; order[m++] = k; }
+    if (m == 0) continue;
+    for (int x = 1; x < m; ++x)
+      for (int y = x; y > 0 && at[order[y]] < at[order[y - 1]]; --y) { const int z = order[y]; order[y] = order[y - 1]; order[y - 1] = z; }
+    fprintf(stderr, "[bt stamps] workgroup %s (us from the P group's frame top; step since the point before):\n", wgn[wg]);
+    for (int x = 0; x < m; ++x)
+      fprintf(stderr, "  %7.2f  %+6.2f  %s\n", at[order[x]], x ? at[order[x]] - at[order[x - 1]] : 0.0, names[order[x]]);
   }
 }
 #endif

@@ -188,6 +188,12 @@ def batch64_record(model, ckpt, device, frames=600, reps=3):
   dec_s = float(np.mean(dec_us)) * 1e-6
   flops = sum(flops_per_frame(model.dims, t) for t in lens) * frames
   achieved = flops / dec_s / 1e12
+  # bytes-based view of the same launch: the weights of a frame once per lockstep frame (16 utterances share them) plus every
+  # utterance's memory, processed memory and state - what a kernel streaming its weights from HBM would move
+  d_ = model.dims
+  per_utt = [t * (d_.A + d_.M) * 4 + (2 * d_.R_a + 2 * d_.R_d + d_.M + d_.P + d_.n_mel + 1 + 2 * t) * 4 for t in lens]
+  lockstep_frames = 64 * frames // 16
+  alg_bytes = model.step_weight_bytes * lockstep_frames + sum(per_utt) * frames
   counters, traffic, src = None, None, latest_profile("r*_lockstep_pmc.json")
   if src:
     prof = json.load(open(src))["derived"]
@@ -208,6 +214,8 @@ def batch64_record(model, ckpt, device, frames=600, reps=3):
                        "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
                        "traffic_source": counters and counters["source"], "counters": counters, "kernel": "taco_decoder_batch_kernel",
                        "flops_per_launch": int(flops), "kernel_ms_per_launch": round(dec_s * 1e3, 4),
+                       "hbm_streaming": {"bytes_per_launch": int(alg_bytes), "achieved_gbs": round(alg_bytes / dec_s / 1e9, 1),
+                                         "peak_gbs": HBM_PEAK_GBS, "frac": round(alg_bytes / dec_s / 1e9 / HBM_PEAK_GBS, 4)},
                        "note": "algorithmic FLOPs (2 x weights touched + attention, per utterance and frame) of the one launch that "
                                "decodes the batch of 64 (16 utterances in flight, slots refilled) / its device time (HIP events on "
                                "the launch stream); exact-f32 matrix-core products run at the f32 vector rate, 1/16 of the bf16 rate"}}

@@ -487,6 +487,25 @@ def test_lockstep_groups_and_long_lines_mix(gate_table):
       assert not mel[b, :, n:].any() and not align[b, :, ln:].any()
 
 
+def _lockstep_schedule(frames, slots=16):
+  """Lockstep frames of one launch by the kernel's rules: utterances are taken in order, sixteen in flight; an utterance
+  of n frames occupies its slot for lockstep frames t0 .. t0 + n - 1, the end is noticed at the top of frame t0 + n, and
+  the next utterance starts in that slot at the next multiple of four; the launch ends at the top of the frame in which no
+  slot holds or awaits an utterance."""
+  queue = list(frames)
+  ends = [None] * slots          # lockstep frame at whose top the slot's utterance is found complete
+  for sl in range(slots):
+    if queue:
+      ends[sl] = queue.pop(0)
+  t = 0
+  while any(e is not None for e in ends):
+    t = min(e for e in ends if e is not None)
+    for sl in range(slots):
+      if ends[sl] == t:
+        ends[sl] = ((t + 3) & ~3) + queue.pop(0) if queue else None
+  return t
+
+
 def test_lockstep_slots_refill_and_results_do_not_depend_on_neighbours(gate_table, monkeypatch):
   """Fifty ragged lines with the stop test live through ONE lockstep launch: sixteen are in flight, and a slot whose
   utterance stops takes the next line at the next lockstep frame that is a multiple of four.  Every line against the checker's run of it alone
@@ -512,6 +531,7 @@ def test_lockstep_slots_refill_and_results_do_not_depend_on_neighbours(gate_tabl
   assert len(set(frames)) > 4 and min(frames) < max_steps and max(frames) == max_steps, "slots are meant to free up at different frames"
   us, lockstep_frames = gm.last_decode_timing()
   assert lockstep_frames < 0.6 * max_steps * ((len(lens) + 15) // 16), "freed slots were not taken over"
+  assert lockstep_frames == _lockstep_schedule(frames), "the launch ran a different number of lockstep frames than its rules give"
   for b, ln in enumerate(lens):
     _, mel_o, gate_o, align_o, n, reached_o = _oracle_single(om, ids, b, ln, masks, max_steps)
     assert frames[b] == n and int(reached[b]) == reached_o, (b, ln, frames[b], n)

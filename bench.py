@@ -14,7 +14,7 @@ With N > 1 (one process per GPU, launched by torch.distributed.run) the workload
 configuration: N x ``--lines-per-gpu`` synthetic lines (T_in ~ U{20..200}, generator seed 2024), every one run
 to ``--frames`` decoder frames, partitioned over the ranks longest-processing-time-first on predicted cost
 (tacotron_amd.sharding, the partition the ``synthesize`` command uses), each rank decoding its shard in padded
-batches of 64 (four lockstep groups of 16).  Utterances are independent: there is no data-path collective and
+batches of 64 (one lockstep launch each, sixteen utterances in flight).  Utterances are independent: there is no data-path collective and
 the ranks only meet at the timing barriers.  One step = one pass over the whole line set; ``value`` is the
 whole-job mel frames per second.  ``--workload lines`` runs the same on one GPU.
 

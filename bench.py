@@ -256,7 +256,7 @@ def lines_workload(model, ckpt, device, world, rank, lines_per_gpu, frames, batc
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
-  ap.add_argument("--steps", type=int, default=20)
+  ap.add_argument("--steps", type=int, default=100)
   ap.add_argument("--warmup", type=int, default=3)
   ap.add_argument("--frames", type=int, default=1000, help="decoder frames per utterance (max_decoder_steps)")
   ap.add_argument("--workload", choices=("auto", "b1", "lines"), default="auto",

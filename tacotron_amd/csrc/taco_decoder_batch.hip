@@ -84,17 +84,6 @@ constexpr int QT = (TIN / 16 + NW - 1) / NW;   // tiles of 16 positions per wave
 constexpr int QR = 16 / NW;            // query rows per wave (4)
 constexpr int LOC_KSTEPS = 16;
 constexpr int RP = TACO_BT_ROWS;       // rows per P / M workgroup (one MFMA tile)
-// Who may wait: a vector that only some workgroups need at once is fetched later by the others (they have the time),
-// so that the L2 serves the ones in a hurry first.  In nap units (four = one s_sleep of 64 clocks).
-#ifndef TACO_BT_LAG_AH
-#define TACO_BT_LAG_AH 0
-#endif
-#ifndef TACO_BT_LAG_DH
-#define TACO_BT_LAG_DH 0
-#endif
-#ifndef TACO_BT_LOC_FIRST
-#define TACO_BT_LOC_FIRST 0
-#endif
 constexpr int W1_KSTEPS = (TACO_MAX_MEL + 3) / 4;    // 20
 static_assert(2 * TACO_MAX_K <= 4 * LOC_KSTEPS, "location taps fit 16 steps of 4");
 static_assert(QR == 4 && QT % 2 == 0 && CPG * CQ <= NT && MEMW % 4 == 0 && NQ * MEMW >= 544, "Q thread maps");
@@ -785,7 +774,6 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
     {
       u32x4 vah[NL_H];
       f32x4 acc_d2 = {0.0f, 0.0f, 0.0f, 0.0f}, acc_an2 = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (!is_q) taco_nap(TACO_BT_LAG_AH);
       bt_nap_begin(nap_ah, wctx);
       if (is_q) {
         // a Q workgroup has the softmax ahead of it and everybody waiting for its context: it takes half of the vector
@@ -1036,8 +1024,6 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
     // ============ the decoder hidden state; P: next frame's layer-1 rows; M: the frame's output ============
     {
       u32x4 vdh[NL_H];
-      if (TACO_BT_LOC_FIRST && is_q) update_location_term(lane_f);
-      if (!is_p && !is_m) taco_nap(TACO_BT_LAG_DH);
       bt_nap_begin(nap_dh, wctx);
       bt_issue<NL_H>(rs, par + w_lane_dh, vdh);
       BT_SB();
@@ -1135,7 +1121,7 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
       }
     }
     // Q: next frame's location term, while the P group works on the next frame's prenet output
-    if (!TACO_BT_LOC_FIRST && is_q) update_location_term(lane_f);
+    if (is_q) update_location_term(lane_f);
     BT_STAMP(14);
   }
 

@@ -142,7 +142,7 @@ int taco_encode(taco_handle h, const int64_t* const* ids, const int64_t* speaker
                 int32_t B, int32_t T_in, float* memory, float* processed_memory, void* stream);
 
 /* Autoregressive decoder: all frames of an utterance inside one persistent launch, no host round trip per frame.
- * Utterances of up to 208 symbols go through the lockstep kernel: ONE launch advances sixteen of them frame by frame
+ * Utterances of up to 224 symbols go through the lockstep kernel: ONE launch advances sixteen of them frame by frame
  * (their LSTM gate rows as matrix-core tiles), and when one stops the next utterance of the call takes its slot, so
  * a large B keeps all sixteen slots busy; an utterance's result there is bit-identical whatever else is in the call.
  * Longer utterances, and an utterance left alone, each get a launch of the batch-1 kernel (same results to 1e-4

@@ -65,7 +65,7 @@ constexpr int TACO_BATCH_NB = 16;       // utterances per lockstep launch = colu
 constexpr int TACO_BT_KP = 256;         // k capacity of the prenet vectors
 constexpr int TACO_BT_KH = 1024;        // ... of the LSTM hidden states
 constexpr int TACO_BT_KC = 576;         // ... of the attention context (M <= 8 * TACO_BT_MEMW = 544)
-constexpr int TACO_BT_TIN = 208;        // symbols per utterance (what the Q workgroups' LDS has room for)
+constexpr int TACO_BT_TIN = 224;        // symbols per utterance (what the Q workgroups' LDS has room for)
 constexpr int TACO_BT_MEMW = 68;        // memory columns per Q workgroup
 constexpr int TACO_BT_ROWS = 16;        // rows per P / M workgroup
 #ifndef TACO_BT_REP

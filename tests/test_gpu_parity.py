@@ -423,7 +423,7 @@ def test_lockstep_teacher_forced_matches_reference(name, monkeypatch):
   ids1 = golden_ids(z)
   n = meta["n_frames"]
   T1 = ids1["symbols"].shape[1]
-  other_lens = [7, min(T1 + 31, 208), 64]
+  other_lens = [7, min(T1 + 31, 224), 64]
   lens = [T1, other_lens[0], T1, other_lens[1], other_lens[2], T1]
   ids = scenarios.random_ids(ck, lens, seed=31)
   for b, ln in enumerate(lens):
@@ -463,10 +463,10 @@ def test_lockstep_teacher_forced_matches_reference(name, monkeypatch):
 
 def test_lockstep_groups_and_long_lines_mix(gate_table):
   """Seventeen-plus utterances (a full group and a part-filled one) with lines on both sides of the lockstep kernel's
-  208-symbol capacity (the long ones run the batch-1 kernel inside the same call), one-symbol lines, a stop on the
+  224-symbol capacity (the long ones run the batch-1 kernel inside the same call), one-symbol lines, a stop on the
   first frames: every utterance against the checker."""
-  for name, lens, max_steps in (("tiny", [208, 209, 1, 300, 16, 2, 207, 64, 33, 512, 5, 100, 3, 256, 9, 77, 150, 12, 200, 41], 14),
-                                ("ljs", [209, 208, 30, 3], 6)):
+  for name, lens, max_steps in (("tiny", [224, 225, 1, 300, 16, 2, 223, 64, 33, 512, 5, 100, 3, 256, 9, 77, 150, 12, 208, 41], 14),
+                                ("ljs", [225, 224, 30, 3], 6)):
     gate = gate_table[name]
     om = oracle_model(name, gate)
     gm = gpu_model(name, gate)

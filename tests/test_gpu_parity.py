@@ -550,6 +550,37 @@ def test_lockstep_slots_refill_and_results_do_not_depend_on_neighbours(gate_tabl
   assert torch.equal(mel_2, mel[pick]) and torch.equal(align_2, align[pick]) and torch.equal(nf_2, nf[pick])
 
 
+def test_lockstep_teacher_forcing_across_refilled_slots(gate_table, monkeypatch):
+  """Teacher forcing with more utterances than slots: every utterance runs exactly max_steps frames, all sixteen slots
+  free up in the same lockstep frame and the remaining lines take them over; forced frames, keep-masks and output columns
+  must follow each utterance's OWN frame count.  Every line against the checker fed the same frames."""
+  gate = gate_table["tiny"]
+  gm = gpu_model("tiny", gate)
+  om = oracle_model("tiny", gate)
+  ck = scenario_checkpoint("tiny", gate)
+  r = np.random.RandomState(21)
+  lens = [int(v) for v in r.randint(2, 225, size=21)]
+  steps = 9
+  ids = scenarios.random_ids(ck, lens, seed=2121)
+  for b in range(len(lens)):
+    ids["speakers"][b, :] = ids["speakers"][b, 0]
+  masks = prenet_keep_masks(3, steps, om.dims.P)
+  lens_d = dev(np.array(lens, np.int32))
+  mem, pm = gm.encode([dev(c) for c in chans(ids)], dev(ids["speakers"]), lens_d)
+  forced = torch.from_numpy(np.random.RandomState(5).randn(len(lens), om.dims.n_mel, steps).astype(np.float32)).to("cuda:0")
+  monkeypatch.setenv("TACO_DECODER", "lockstep")
+  mel, gate_g, align, nf, reached = gm.decode(mem, pm, lens_d, masks, steps, forced_mel=forced)
+  assert nf.cpu().tolist() == [steps] * len(lens)
+  assert gm.last_decode_timing()[1] == _lockstep_schedule([steps] * len(lens))
+  for b, ln in enumerate(lens):
+    one = {k: (None if v is None else v[b:b + 1, :ln]) for k, v in ids.items() if k != "lens"}
+    mem_o, pm_o = om.encode(chans(one), one["speakers"], None)
+    mel_o, gate_o, align_o, nf_o, _, _ = om.decode(mem_o, pm_o, None, masks.numpy(), steps, forced_mel=forced[b:b + 1].cpu().numpy())
+    np.testing.assert_allclose(mel[b].cpu().numpy(), mel_o[0], atol=TF_TOL, rtol=0, err_msg=f"utterance {b}")
+    np.testing.assert_allclose(gate_g[b].cpu().numpy(), gate_o[0], atol=TF_TOL, rtol=0)
+    np.testing.assert_allclose(align[b, :, :ln].cpu().numpy(), align_o[0], atol=TF_TOL, rtol=0)
+
+
 def test_full_size_properties(gate_table):
   """Size-independent checks at the benchmark's extents (1000 frames of the LJS-sized model):
   bit-reproducibility, the prefix property (fewer allowed steps = a prefix of the longer run),

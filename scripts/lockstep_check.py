@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Development check of the lockstep decoder against the CPU checker (oracle): a ragged batch through
-taco_decode (which groups utterances of up to 256 symbols sixteen to a launch), each utterance compared
+taco_decode (one lockstep launch for the lines of up to 224 symbols, sixteen in flight), each utterance compared
 with the oracle's run of the same line alone.  Usage: lockstep_check.py [tiny|ljs|thchs] [B] [frames] [forced]"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -108,6 +108,7 @@ class Synthesizer:
                       n_durations=count(self.duration_mapping))
     model.load_state_dict(checkpoint[KEY_MODEL_STATE])
     self.model = model.to(self.device).eval()
+    self._staging: Dict[int, torch.Tensor] = {}
 
   def get_sampling_rate(self) -> int:
     return self.hparams.sampling_rate
@@ -115,6 +116,21 @@ class Synthesizer:
   def _sync(self) -> None:
     if self.device.type == "cuda":
       torch.cuda.synchronize(self.device)
+
+  def _to_host(self, t: torch.Tensor, which: int) -> np.ndarray:
+    """Copies a device tensor into a page-locked staging buffer kept per output array (a pageable destination makes
+    the runtime bounce the copy through its own small pinned buffers at a fraction of the link's rate) and returns
+    the buffer as an array: valid until the next call with the same ``which``."""
+    if t.device.type != "cuda":
+      return t.contiguous().numpy()
+    have = self._staging.get(which)
+    if have is None or have.numel() < t.numel():
+      have = torch.empty(max(t.numel(), 1), dtype=t.dtype, pin_memory=True)
+      self._staging[which] = have
+    dst = have[:t.numel()].view(t.shape)
+    dst.copy_(t, non_blocking=True)
+    self._sync()
+    return dst.numpy()
 
   # ---- host logic: symbols -> ids, dropping positions no mapping knows ---------------------------
   def _prepare(self, symbols: Sequence[str], speaker: Optional[str]) -> _Prepared:
@@ -223,10 +239,10 @@ class Synthesizer:
     def padded(name):
       if preps[0].ids[name] is None:
         return None
-      out = torch.zeros(len(preps), T, dtype=torch.int64)
+      out = np.zeros((len(preps), T), dtype=np.int64)
       for b, p in enumerate(preps):
-        out[b, :lens[b]] = torch.tensor(p.ids[name], dtype=torch.int64)
-      return out.to(self.device)
+        out[b, :lens[b]] = p.ids[name]
+      return torch.from_numpy(out).to(self.device)
 
     speakers = None
     if self.hparams.use_speaker_embedding:
@@ -244,12 +260,13 @@ class Synthesizer:
     if not keep_on_device:
       # one copy per array for the whole batch (up to its longest utterance), sliced per line on the host
       n_max = max(n_frames)
-      post = post[:, :, :n_max].cpu().numpy()
+      post = self._to_host(post[:, :, :n_max], 0)
       if include_stats:
-        mel, gate, align = mel[:, :, :n_max].cpu().numpy(), gate[:, :n_max].cpu().numpy(), align[:, :n_max].cpu().numpy()
+        mel, gate, align = (self._to_host(mel[:, :, :n_max], 1), self._to_host(gate[:, :n_max], 2),
+                            self._to_host(align[:, :n_max], 3))
 
     def own(a):
-      return a if keep_on_device else np.ascontiguousarray(a)
+      return a if keep_on_device else a.copy()     # the staging buffers are reused by the next batch
 
     out = []
     for b, p in enumerate(preps):

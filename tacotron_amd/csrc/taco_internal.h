@@ -119,6 +119,7 @@ struct taco_handle_s {
   // workspaces (grow-only)
   float* ws_act[2];          // activation ping-pong [B][C_max][T]
   size_t ws_act_floats;
+  float* conv_split;         // partial tiles and tile counters of the convolutions whose tiles are shared by several workgroups
   float* ws_gx;              // [B][2][4*H_e][T] LSTM input projections
   size_t ws_gx_floats;
   taco_granule* enc_gran;    // encoder LSTM hand-off words
@@ -152,7 +153,12 @@ int taco_launch_embed(taco_handle h, const int64_t* const* ids_dev, const int32_
 // columns >= lens[b] are written as zero.
 int taco_launch_conv(const float* in, float* out, const float* w, const float* bias, const float* alpha,
                      const float* beta, const float* residual, const int32_t* lens, int B, int c_in,
-                     int c_out, int k, int T, int act, int layout, hipStream_t s);
+                     int c_out, int k, int T, int act, int layout, float* split_ws, int n_cu, hipStream_t s);
+// split_ws: workspace of taco_conv_split_floats() floats (partial tiles, then one counter per tile; the counters must
+// be zero when the first launch uses them and every launch leaves them zero), or NULL = every tile by one workgroup.
+// Launches that share a workspace must not overlap.
+constexpr int TACO_CONV_SPLIT_SLABS = 512;                   // partial tiles of 32 x 64 floats
+constexpr size_t taco_conv_split_floats() { return (size_t)TACO_CONV_SPLIT_SLABS * 2048 + TACO_CONV_SPLIT_SLABS; }
 int taco_conv_prepare();
 int taco_launch_enc_lstm(taco_handle h, const float* gx, const int32_t* lens, int B, int T, float* memory,
                          hipStream_t s);

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void taco_conv_kernel(const float* __restrict_
                                                         const float* __restrict__ alpha, const float* __restrict__ beta,
                                                         const float* __restrict__ residual, const int32_t* lens,
                                                         int c_in, int c_out, int T, int act, int layout,
-                                                        const float* __restrict__ zero_word) {
+                                                        const float* __restrict__ zero_word, int split, float* split_ws) {
   constexpr bool in_time_major = IN_TM;          // input is [T][C] instead of [C][T]
   const bool out_time_major = layout & 2;        // output likewise
   constexpr int CI = taco_conv_ci(KS);         // input channels per slab
@@ -95,7 +95,11 @@ __global__ __launch_bounds__(256) void taco_conv_kernel(const float* __restrict_
   const int thalf = wave & 1, khalf = wave >> 1;
   const int i = lane & 31, h = lane >> 5;
   const int b = blockIdx.z;
-  const int t0 = blockIdx.x * CV_TT;
+  // split > 1: `split` consecutive workgroups share an output tile, each with its own range of slabs (see the end of
+  // the slab loop for how their partial tiles meet)
+  const int tile_t = split > 1 ? blockIdx.x / split : blockIdx.x;
+  const int ksl = split > 1 ? blockIdx.x % split : 0;
+  const int t0 = tile_t * CV_TT;
   const int co0 = blockIdx.y * CV_CO;
   const int len = lens ? lens[b] : T;
   const float* in_b = in + (size_t)b * c_in * T;
@@ -146,12 +150,14 @@ __global__ __launch_bounds__(256) void taco_conv_kernel(const float* __restrict_
         for (int n = 0; n < NX; ++n)
           if (seg + 8 * n < XW) xs[buf][srow + 32 * q][seg + 8 * n] = px[q][n];
     };
-    const int n_slabs = (c_in + CI - 1) / CI;
+    const int n_slabs_all = (c_in + CI - 1) / CI;
+    const int sl0 = ksl * n_slabs_all / split;                     // my slabs: sl0 .. sl0 + n_slabs - 1 (at least one)
+    const int n_slabs = (ksl + 1) * n_slabs_all / split - sl0;
     // one slab: fetch slab s+2 into `fetch`, multiply slab s (LDS buffer s&1), park slab s+1 (`park`, fetched
     // one slab ago) in the other LDS buffer
     auto slab = [&](int s, float (&fw)[NW], float (&fx)[XR][NX], const float (&kw)[NW], const float (&kx)[XR][NX]) {
       const int buf = s & 1;
-      load_slab(min(s + 2, n_slabs - 1) * CI, fw, fx);      // past the end: a harmless reload of the last slab
+      load_slab((sl0 + min(s + 2, n_slabs - 1)) * CI, fw, fx);      // past the end: a harmless reload of the last slab
       // operands of step+1 are read from LDS while the MFMAs of step run (two register sets)
       float av[2][KS], bv[2][KS];
       auto read_operands = [&](int step, int set) {
@@ -173,8 +179,8 @@ __global__ __launch_bounds__(256) void taco_conv_kernel(const float* __restrict_
       store_slab(buf ^ 1, kw, kx);
       __syncthreads();
     };
-    load_slab(0, pwA, pxA);
-    load_slab(min(1, n_slabs - 1) * CI, pwB, pxB);
+    load_slab(sl0 * CI, pwA, pxA);
+    load_slab((sl0 + min(1, n_slabs - 1)) * CI, pwB, pxB);
     store_slab(0, pwA, pxA);
     __syncthreads();
     for (int s = 0; s < n_slabs; s += 2) {
@@ -191,6 +197,53 @@ __global__ __launch_bounds__(256) void taco_conv_kernel(const float* __restrict_
     if (khalf == 0) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] += red[(thalf * 16 + r) * 64 + lane];
+    }
+    if (split > 1) {
+      // The workgroups of a tile leave their partial tiles in global memory (write-through 16-byte stores, so no release
+      // fence is needed), draw a ticket from the tile's counter, and the one that draws the last ticket adds all the
+      // partial tiles - its own included, from memory, in slab order, so the sum does not depend on who came last - and
+      // goes on to the epilogue.  It also puts the counter back to zero for the next launch that uses it.
+      // Partial tile of slice k of tile n: floats [(n * split + k) * 2048 ..), as [column half][register quad][lane][4].
+      const unsigned tiles_t = gridDim.x / (unsigned)split;
+      const unsigned tile = ((unsigned)b * gridDim.y + blockIdx.y) * tiles_t + (unsigned)tile_t;
+      const unsigned n_part = gridDim.z * gridDim.y * tiles_t * (unsigned)split;
+      typedef unsigned taco_u4 __attribute__((ext_vector_type(4)));
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)split_ws, 0, (int)(n_part * (CV_CO * CV_TT * 4u)), 0x00020000);
+      unsigned* counters = reinterpret_cast<unsigned*>(split_ws + (size_t)TACO_CONV_SPLIT_SLABS * (CV_CO * CV_TT));
+      const unsigned lane_off = ((unsigned)thalf * 4u * 64u + (unsigned)lane) * 16u;
+      if (khalf == 0) {
+        const unsigned at = (tile * (unsigned)split + (unsigned)ksl) * (CV_CO * CV_TT * 4u) + lane_off;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const taco_u4 v = {__float_as_uint(acc[4 * q]), __float_as_uint(acc[4 * q + 1]), __float_as_uint(acc[4 * q + 2]),
+                             __float_as_uint(acc[4 * q + 3])};
+          __builtin_amdgcn_raw_buffer_store_b128(v, rs, at + (unsigned)q * 1024u, 0, 16 /* sc1: write-through */);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave's stores have been acknowledged
+      __syncthreads();
+      unsigned* ticket_lds = reinterpret_cast<unsigned*>(conv_lds);      // the input buffers are no longer in use
+      if (tid == 0) *ticket_lds = __hip_atomic_fetch_add(counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      if (*ticket_lds != (unsigned)split - 1u) return;
+      if (tid == 0) __hip_atomic_store(counters + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (khalf == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        for (int k = 0; k < split; ++k) {
+          const unsigned at = (tile * (unsigned)split + (unsigned)k) * (CV_CO * CV_TT * 4u) + lane_off;
+          taco_u4 v[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, at + (unsigned)q * 1024u, 0, 16 /* sc1: past this CU's L1 */);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            acc[4 * q] += __uint_as_float(v[q].x);
+            acc[4 * q + 1] += __uint_as_float(v[q].y);
+            acc[4 * q + 2] += __uint_as_float(v[q].z);
+            acc[4 * q + 3] += __uint_as_float(v[q].w);
+          }
+        }
+      }
     }
   }
   if (khalf != 0) return;
@@ -451,23 +504,41 @@ int taco_conv_prepare() {
   return TACO_OK;
 }
 
+// How many workgroups share an output tile.  A convolution with fewer tiles than the device has CUs runs at the latency
+// of one workgroup's serial slab loop, so the loop is cut into up to 8 ranges of at least two slabs each, as long as the
+// launch stays within one workgroup per CU (and within the partial-tile workspace).  Measured on the encoder
+// (102 symbols: 34 tiles -> 7 workgroups each, 37 -> 20 us per layer) and the postnet (250 frames: 171 -> 95 us for
+// the five layers; 1000 frames: the 80-channel last layer 41 -> 23 us); filling the device twice or cutting the
+// 256-tile layers in two gained nothing: two workgroups on a CU take as long as one with twice the slabs.
+static int taco_conv_split_factor(int base_tiles, int n_slabs, int n_cu) {
+  int split = n_cu / (base_tiles > 0 ? base_tiles : 1);
+  if (split > 8) split = 8;
+  if (split > n_slabs / 2) split = n_slabs / 2;
+  while (split > 1 && (size_t)base_tiles * split > (size_t)TACO_CONV_SPLIT_SLABS) --split;
+  if (base_tiles > TACO_CONV_SPLIT_SLABS) split = 1;
+  return split < 1 ? 1 : split;
+}
+
 int taco_launch_conv(const float* in, float* out, const float* w, const float* bias, const float* alpha,
                      const float* beta, const float* residual, const int32_t* lens, int B, int c_in,
-                     int c_out, int k, int T, int act, int layout, hipStream_t s) {
+                     int c_out, int k, int T, int act, int layout, float* split_ws, int n_cu, hipStream_t s) {
   int dev = 0;
   TACO_HIP(hipGetDevice(&dev));
   const float* zero = (dev >= 0 && dev < 64) ? g_conv_zero[dev] : nullptr;
   if (!zero) TACO_FAIL(TACO_EINVAL, "taco_conv_prepare has not run on device %d", dev);
-  const dim3 grid((T + CV_TT - 1) / CV_TT, (c_out + CV_CO - 1) / CV_CO, B);
+  const int tiles_t = (T + CV_TT - 1) / CV_TT, tiles_co = (c_out + CV_CO - 1) / CV_CO;
+  const int ci = taco_conv_ci(k);
+  const int split = split_ws ? taco_conv_split_factor(tiles_t * tiles_co * B, (c_in + ci - 1) / ci, n_cu) : 1;
+  const dim3 grid(tiles_t * split, tiles_co, B);
   switch (k) {
 #define TACO_CONV_CASE(KS)                                                                          \
   case KS:                                                                                          \
     if (layout & 1)                                                                                 \
       hipLaunchKernelGGL((taco_conv_kernel<KS, true>), grid, dim3(256), taco_conv_lds_bytes(KS), s, in, out, w, bias, alpha, beta, \
-                         residual, lens, c_in, c_out, T, act, layout, zero);                        \
+                         residual, lens, c_in, c_out, T, act, layout, zero, split, split_ws);       \
     else                                                                                            \
     hipLaunchKernelGGL((taco_conv_kernel<KS, false>), grid, dim3(256), taco_conv_lds_bytes(KS), s, in, out, w, bias, alpha, beta,  \
-                       residual, lens, c_in, c_out, T, act, layout, zero);                              \
+                       residual, lens, c_in, c_out, T, act, layout, zero, split, split_ws);             \
     break;
     TACO_CONV_CASE(1)
     TACO_CONV_CASE(3)
@@ -534,5 +605,5 @@ int taco_launch_memory_tail(taco_handle h, const int64_t* speakers, const int32_
   TACO_HIP(hipGetLastError());
   // processed_memory = memory_layer(memory): a kernel-size-1 convolution, position-major in and out
   return taco_launch_conv(memory, pm, h->w.memory_w, nullptr, nullptr, nullptr, nullptr, lens, B, d.M, d.A, 1, T, 0,
-                          /*position-major in and out*/ 3, s);
+                          /*position-major in and out*/ 3, h->conv_split, h->n_cu, s);
 }

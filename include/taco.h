@@ -188,8 +188,9 @@ int taco_postnet(taco_handle h, const float* mel, const int32_t* n_frames, int32
 
 /* taco_postnet for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
  * harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same arguments and result as
- * taco_postnet, but the layer activations live in a scratch area built into the library (8 MiB per device, held until
- * the process ends) instead of the handle's grow-only workspace, and the call makes no hipMalloc / hipFree:
+ * taco_postnet, but the layer activations and the convolutions' partial tiles live in a scratch area built into the
+ * library (12 MiB per device: 8 MiB of activations, 4 MiB of partial tiles; held until the process ends) instead of
+ * the handle's workspaces, and the call makes no hipMalloc / hipFree:
  *   limit   B * max(C_post, n_mel) * T_cap <= 512 * TACO_NOALLOC_COLS floats, else TACO_EINVAL;
  *   sharing every call on a device uses that device's one scratch area: calls that overlap on one GPU (two streams,
  *           two handles) race; calls on one stream are ordered like any other work on it. */

@@ -24,7 +24,7 @@ extern "C" const char* taco_version(void) { return "taco-hip 0.1 gfx950"; }
 
 // ---- scratch of the entry point that allocates nothing (taco_postnet_noalloc) ----
 // Two activation buffers of up to TACO_NOALLOC_COLS columns x 512 channels each, inside the code object: every device
-// the library runs on holds its own copy (8 MiB) until the process ends.  The name below is a host-side stand-in, not
+// the library runs on holds its own copy (8 MiB, 12 with the workspace that follows them) until the process ends.  The name below is a host-side stand-in, not
 // a device address: taco_create asks for the address once per device, with that device current, and every use goes
 // through the pointer kept here.
 #define TACO_NOALLOC_HALF (512u * (unsigned)TACO_NOALLOC_COLS)

@@ -119,3 +119,36 @@ def test_results_can_stay_on_the_device(gate_table):
       a, b = getattr(h, name), getattr(d, name)
       assert isinstance(b, torch.Tensor) and b.is_cuda and tuple(b.shape) == a.shape
       assert np.array_equal(b.cpu().numpy(), a)
+
+
+# The reference's only test of this path (src/tacotron_tests/synthesizer_py/test_Synthesizer.py:11-46) needs the
+# published checkpoint 101000.pt, which that test downloads to /tmp/tacotron-test.pt.  Nothing can be downloaded
+# here, so the test below runs when that file (or the one TACO_REFERENCE_CHECKPOINT names) is present and is
+# skipped otherwise; the expected values are the reference test's own constants.
+_KAT_TEXT = ('ð|ˈɪ|s|SIL0|ˈɪ|z|SIL0|ə|SIL0|tː|ˈɛ|s|t|SIL0|ˈæ|b|?|SIL2|ə|n˘|d|SIL0|ˈaɪ˘|m|SIL0|ð|ˈɛr˘|SIL0|θ|ˈʌr|d˘|ˌi|-|wː|ˈʌː|nː|.|SIL2')
+_KAT_CORNER = np.array([
+  [-6.9595537, -6.7366004, -6.482799, -6.498109, -6.52342],
+  [-6.557069, -6.060888, -5.713961, -5.7108502, -5.830424],
+  [-5.943193, -5.374925, -4.958975, -4.860589, -5.1093984],
+  [-5.288998, -4.7378426, -4.6273413, -4.6779313, -5.0058713],
+  [-4.703808, -3.656827, -3.7665925, -4.4009595, -4.8536625]], dtype=np.float32)
+
+
+def test_reference_component_test_on_the_published_checkpoint():
+  path = os.environ.get("TACO_REFERENCE_CHECKPOINT", "/tmp/tacotron-test.pt")
+  if not os.path.isfile(path):
+    pytest.skip(f"the reference's published checkpoint is not at {path} (it cannot be downloaded here)")
+  from tacotron_amd.checkpoint import load_checkpoint
+  from tacotron_amd.synthesizer import Synthesizer
+  s = Synthesizer(load_checkpoint(path, device="cpu"), device="cuda:0")
+  result = s.infer(_KAT_TEXT.split("|"), "Linda Johnson", seed=0)
+  assert result.sampling_rate == 22050
+  assert result.reached_max_decoder_steps is False
+  assert result.unmappable_durations is None and result.unmappable_stresses is None
+  assert result.unmappable_symbols is None and result.unmappable_tones is None
+  assert result.mel_outputs_postnet.shape == (80, 214)           # the stop frame is the reference's
+  # the reference compares to 6 decimals with its own PyTorch build; the free-running bound of this suite applies here
+  np.testing.assert_allclose(result.mel_outputs_postnet[:5, :5], _KAT_CORNER, atol=FREE_TOL, rtol=0)
+  assert result.mel_outputs is None and result.gate_outputs is None and result.alignments is None
+  assert result.duration_s == 2.4729251700680273
+  assert result.inference_duration_s > 0

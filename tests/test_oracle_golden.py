@@ -115,3 +115,20 @@ def test_generator_reproduces_committed_checkpoint(gate_table):
 
 def test_north_wind_line_has_102_symbols():
   assert len(scenarios.NORTH_WIND_SYMBOLS) == 102
+
+
+def test_oracle_on_the_published_checkpoint_matches_the_reference_component_test():
+  """The reference's own known-answer test (src/tacotron_tests/synthesizer_py/test_Synthesizer.py:11-46) against the
+  oracle.  It needs the published checkpoint, which the reference's test downloads to /tmp/tacotron-test.pt; nothing
+  can be downloaded here, so the test runs only where that file (or the one TACO_REFERENCE_CHECKPOINT names) exists."""
+  path = os.environ.get("TACO_REFERENCE_CHECKPOINT", "/tmp/tacotron-test.pt")
+  if not os.path.isfile(path):
+    pytest.skip(f"the reference's published checkpoint is not at {path} (it cannot be downloaded here)")
+  from oracle_shim import oracle_synthesizer
+  from tacotron_amd.checkpoint import load_checkpoint
+  from test_gpu_workflows import _KAT_CORNER, _KAT_TEXT
+  result = oracle_synthesizer(load_checkpoint(path, device="cpu")).infer(_KAT_TEXT.split("|"), "Linda Johnson", seed=0)
+  assert result.reached_max_decoder_steps is False and result.unmappable_symbols is None
+  assert result.mel_outputs_postnet.shape == (80, 214)
+  np.testing.assert_allclose(result.mel_outputs_postnet[:5, :5], _KAT_CORNER, atol=1e-4, rtol=0)
+  assert result.duration_s == 2.4729251700680273

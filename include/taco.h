@@ -210,6 +210,20 @@ int taco_last_decode_timing(taco_handle h, double* total_us, int32_t* frames);
  * ticks = NULL).  Differences of consecutive entries x 10 ns are the latencies of the individual frames. */
 int taco_set_frame_clock(taco_handle h, uint64_t* ticks, int32_t capacity);
 
+/* Arithmetic of the lockstep decoder's LSTM gate products (the decoder of batches; the batch-1 decoder, the encoder and
+ * the postnet always compute in fp32).  The reference computes in fp32 only (src/tacotron/model.py:454-491 runs on the
+ * checkpoint's fp32 tensors); the bf16 setting has no counterpart there and is never chosen by the library itself.
+ *   TACO_PRECISION_F32   exact-f32 matrix-core products, results within the fp32 parity bounds (default);
+ *   TACO_PRECISION_BF16  the gate rows of both LSTM cells are kept as bf16 and multiplied with the hidden states,
+ *                        prenet outputs and contexts rounded to bf16 (fp32 accumulation, fp32 cell states and
+ *                        gates): faster, mel frames within 2e-3 of the reference's under teacher forcing
+ *                        (measured 4.4e-4 over 1000 frames), and the stop frame of a free-running utterance
+ *                        may differ from the fp32 one.
+ * Takes effect from the next taco_decode on the handle; any other value returns TACO_EINVAL. */
+#define TACO_PRECISION_F32 0
+#define TACO_PRECISION_BF16 1
+int taco_set_precision(taco_handle h, int32_t precision);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Throughput of a padded batch (default: 64 synthetic lines of 40..160 symbols, generator seed 2024, sorted by
-length, every utterance forced to run `frames` decoder steps) through encode + decode + postnet."""
+length, every utterance forced to run `frames` decoder steps) through encode + decode + postnet.
+TACO_PRECISION=bf16 switches the lockstep decoder to its bf16 setting."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -15,6 +16,8 @@ reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 ckpt = scenarios.checkpoint("ljs")
 hp = get_hparams(ckpt)
 m = Tacotron2(hp, **abi.mapping_counts(ckpt, hp)); m.load_state_dict(ckpt["model_state"]); m.to("cuda:0")
+if os.environ.get("TACO_PRECISION"):
+  m.set_precision(os.environ["TACO_PRECISION"])
 lens = sorted(np.random.RandomState(2024).randint(40, 161, size=B).tolist(), reverse=True)
 ids = scenarios.random_ids(ckpt, lens, seed=2024)
 d = lambda a: None if a is None else torch.from_numpy(a).to("cuda:0")
@@ -36,5 +39,5 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / reps
 total = int(nf.sum())
 us, _ = m.last_decode_timing()
-print(f"B={B}, T_in {min(lens)}..{max(lens)}, {frames} frames each: {dt * 1e3:.1f} ms per batch = {total / dt:.0f} frames/s "
+print(f"[{getattr(m, 'precision', 'fp32')}] B={B}, T_in {min(lens)}..{max(lens)}, {frames} frames each: {dt * 1e3:.1f} ms per batch = {total / dt:.0f} frames/s "
       f"({dt / B * 1e3:.2f} ms per utterance; decoder launches {us / 1e3:.1f} ms = {us / total:.2f} us/frame)")

@@ -20,7 +20,7 @@ CSRC_DIR = os.path.join(_PKG_DIR, "csrc")
 EXPORTED_SYMBOLS = (
   "taco_last_error", "taco_version", "taco_create", "taco_destroy", "taco_step_weight_bytes",
   "taco_encode", "taco_encode_status", "taco_decode", "taco_postnet", "taco_postnet_noalloc", "taco_last_decode_timing",
-  "taco_set_frame_clock",
+  "taco_set_frame_clock", "taco_set_precision",
 )
 
 _lib: Optional[C.CDLL] = None
@@ -66,6 +66,7 @@ def lib() -> C.CDLL:
   L.taco_postnet_noalloc.argtypes = [vp, vp, vp, i32, i32, vp, vp]
   L.taco_last_decode_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i32)]
   L.taco_set_frame_clock.argtypes = [vp, vp, i32]
+  L.taco_set_precision.argtypes = [vp, i32]
   _lib = L
   return L
 

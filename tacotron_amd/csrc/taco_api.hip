@@ -564,6 +564,13 @@ extern "C" int taco_set_frame_clock(taco_handle h, uint64_t* ticks, int32_t capa
   return TACO_OK;
 }
 
+extern "C" int taco_set_precision(taco_handle h, int32_t precision) {
+  if (!h) TACO_FAIL(TACO_EINVAL, "null handle");
+  if (precision != TACO_PRECISION_F32 && precision != TACO_PRECISION_BF16) TACO_FAIL(TACO_EINVAL, "unknown precision %d", precision);
+  h->bat_bf16 = precision == TACO_PRECISION_BF16 ? 1 : 0;
+  return TACO_OK;
+}
+
 extern "C" int taco_last_decode_timing(taco_handle h, double* total_us, int32_t* frames) {
   if (!h || !h->timing_valid) TACO_FAIL(TACO_EINVAL, "no decode has been timed on this handle");
   TACO_HIP(hipEventSynchronize(h->ev_stop));

@@ -59,7 +59,11 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(1))) unsigned int bt_gword;
 
 constexpr int NT = TACO_BT_THREADS;
@@ -279,13 +283,49 @@ __device__ __forceinline__ void bt_nap_begin(int nap, taco_wait_ctx& ctx) {
   asm volatile("" ::: "memory");
 }
 
-// 4 k-steps of one load against 4 weight registers: two independent accumulation chains
-#define BT_MFMA4(W, i, V, accA, accB)                                                              \
+// Four fp32 values -> four bf16 (round to nearest even), the operand of one v_mfma_f32_16x16x16_bf16: lane (l & 15, l >> 4)
+// supplies k = 4 (l >> 4) .. + 3 of a 16-deep step - the four consecutive k a lane's 16-byte load holds anyway.
+__device__ __forceinline__ unsigned bt_pk2(float a, float b) {
+  const f32x2 f = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2));
+}
+__device__ __forceinline__ s16x4 bt_pack(float a, float b, float c, float d) {
+  const u32x2 r = {bt_pk2(a, b), bt_pk2(c, d)};
+  return __builtin_bit_cast(s16x4, r);
+}
+__device__ __forceinline__ s16x4 bt_pack(u32x4 v) { return bt_pack(BT_F(v.x), BT_F(v.y), BT_F(v.z), BT_F(v.w)); }
+
+// The LSTM gate rows a lane keeps for the whole launch, NL 16-byte loads' worth of columns: 4 NL fp32 A operands of
+// 4-deep steps, or (BF) NL bf16 A operands of 16-deep steps - the same columns in half the registers.
+template <bool BF, int NL>
+struct BtRows {
+  float f[BF ? 1 : 4 * NL];
+  s16x4 h[BF ? NL : 1];
+};
+
+// 4 k-steps of one load: four exact-f32 products on two independent accumulation chains, or (BF) one bf16 product
+// (16 deep, a quarter of the issue slots and an eighth of the matrix-core time).  W: BtRows; W4: the four weights as a float4.
+#define BT_MFMA4F(W, i, V, accA, accB)                                                             \
   accA = __builtin_amdgcn_mfma_f32_16x16x4f32(W[4 * (i) + 0], BT_F(V.x), accA, 0, 0, 0);           \
   accB = __builtin_amdgcn_mfma_f32_16x16x4f32(W[4 * (i) + 1], BT_F(V.y), accB, 0, 0, 0);           \
   accA = __builtin_amdgcn_mfma_f32_16x16x4f32(W[4 * (i) + 2], BT_F(V.z), accA, 0, 0, 0);           \
   accB = __builtin_amdgcn_mfma_f32_16x16x4f32(W[4 * (i) + 3], BT_F(V.w), accB, 0, 0, 0);
+#define BT_MFMA4(W, i, V, accA, accB)                                                              \
+  if constexpr (BF) {                                                                              \
+    if ((i) & 1) accB = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k((W).h[i], bt_pack(V), accB, 0, 0, 0);      \
+    else accA = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k((W).h[i], bt_pack(V), accA, 0, 0, 0);    \
+  } else {                                                                                         \
+    BT_MFMA4F((W).f, i, V, accA, accB)                                                             \
+  }
+#define BT_MFMA4S(W4, V, accA, accB)                                                               \
+  if constexpr (BF) {                                                                              \
+    accA = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bt_pack((W4).x, (W4).y, (W4).z, (W4).w), bt_pack(V), accA, 0, 0, 0); \
+  } else {                                                                                         \
+    const float w4_[4] = {(W4).x, (W4).y, (W4).z, (W4).w};                                         \
+    BT_MFMA4F(w4_, 0, V, accA, accB)                                                               \
+  }
 
+template <bool BF>
 __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(const BatArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
@@ -329,23 +369,53 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
   const int hid_a = j * 4 + (row16 >> 2), gate_a = row16 & 3;
   const bool own_a = hid_a < Ra, own_d = hid_a < Rd;
   const size_t ra = (size_t)gate_a * Ra + hid_a, rd = (size_t)gate_a * Rd + hid_a;
-  float wa_h[4 * NL_H];
-  float wd_a[4 * NL_H], wd_c[4 * NL_C], wd_h[4 * NL_H];
+  BtRows<BF, NL_H> wa_h, wd_a, wd_h;
+  BtRows<BF, NL_C> wd_c;
 #define BT_K(NL, s) (16 * (wave * (NL) + ((s) >> 2)) + 4 * kq + ((s) & 3))
+  if constexpr (BF) {
 #pragma unroll
-  for (int i = 0; i < 4 * NL_C; ++i) {
-    const int k = BT_K(NL_C, i);
-    wd_c[i] = (own_d && k < M) ? a.dec_w_ih[rd * (Ra + M) + Ra + k] : 0.0f;
-    if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
-  }
-  __builtin_amdgcn_sched_barrier(0);
+    for (int li = 0; li < NL_C; ++li) {
+      float v[4];
 #pragma unroll
-  for (int i = 0; i < 4 * NL_H; ++i) {
-    const int k = BT_K(NL_H, i);
-    wa_h[i] = (own_a && k < Ra) ? a.att_w_hh[ra * Ra + k] : 0.0f;
-    wd_a[i] = (own_d && k < Ra) ? a.dec_w_ih[rd * (Ra + M) + k] : 0.0f;
-    wd_h[i] = (own_d && k < Rd) ? a.dec_w_hh[rd * Rd + k] : 0.0f;
-    if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+      for (int e = 0; e < 4; ++e) {
+        const int k = BT_K(NL_C, 4 * li + e);
+        v[e] = (own_d && k < M) ? a.dec_w_ih[rd * (Ra + M) + Ra + k] : 0.0f;
+      }
+      wd_c.h[li] = bt_pack(v[0], v[1], v[2], v[3]);
+      if ((li & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int li = 0; li < NL_H; ++li) {
+      float va[4], vd[4], vh[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = BT_K(NL_H, 4 * li + e);
+        va[e] = (own_a && k < Ra) ? a.att_w_hh[ra * Ra + k] : 0.0f;
+        vd[e] = (own_d && k < Ra) ? a.dec_w_ih[rd * (Ra + M) + k] : 0.0f;
+        vh[e] = (own_d && k < Rd) ? a.dec_w_hh[rd * Rd + k] : 0.0f;
+      }
+      wa_h.h[li] = bt_pack(va[0], va[1], va[2], va[3]);
+      wd_a.h[li] = bt_pack(vd[0], vd[1], vd[2], vd[3]);
+      wd_h.h[li] = bt_pack(vh[0], vh[1], vh[2], vh[3]);
+      if ((li & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4 * NL_C; ++i) {
+      const int k = BT_K(NL_C, i);
+      wd_c.f[i] = (own_d && k < M) ? a.dec_w_ih[rd * (Ra + M) + Ra + k] : 0.0f;
+      if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4 * NL_H; ++i) {
+      const int k = BT_K(NL_H, i);
+      wa_h.f[i] = (own_a && k < Ra) ? a.att_w_hh[ra * Ra + k] : 0.0f;
+      wd_a.f[i] = (own_d && k < Ra) ? a.dec_w_ih[rd * (Ra + M) + k] : 0.0f;
+      wd_h.f[i] = (own_d && k < Rd) ? a.dec_w_hh[rd * Rd + k] : 0.0f;
+      if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+    }
   }
 #undef BT_K
 
@@ -596,7 +666,7 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
         BT_SB();
         f32x4 acc2 = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int i = 0; i < NL_P; ++i) { BT_MFMA4(aop, i, v[i], acc, acc2) }
+        for (int i = 0; i < NL_P; ++i) { BT_MFMA4F(aop, i, v[i], acc, acc2) }
         acc += acc2;
       }
       acc = bt_reduce_tiles(lds, LP_RED, acc, wave, lane_f);
@@ -697,10 +767,7 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
       BT_STAMP(2);
       f32x4 acc2 = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-      for (int i = 0; i < NL_P; ++i) {
-        const float wp[4] = {wp4[i].x, wp4[i].y, wp4[i].z, wp4[i].w};
-        BT_MFMA4(wp, 0, v[i], acc_a, acc2)
-      }
+      for (int i = 0; i < NL_P; ++i) { BT_MFMA4S(wp4[i], v[i], acc_a, acc2) }
       acc_a += acc2;
       const f32x4 pre = bt_reduce_tiles(lds, L_RED, acc_a, wave, lane_f);
       if (wave == 0) {
@@ -1017,17 +1084,14 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
           float aop[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) aop[e] = crow[(4 * i + e) * 64];
-          BT_MFMA4(aop, 0, vc[i], acc_r, acc_r2)
+          BT_MFMA4F(aop, 0, vc[i], acc_r, acc_r2)
         }
       }
       // ... and the context columns of next frame's attention LSTM
       acc_a = acc_an;
       f32x4 acc_a2 = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-      for (int i = 0; i < NL_C; ++i) {
-        const float wc[4] = {wc4[i].x, wc4[i].y, wc4[i].z, wc4[i].w};
-        BT_MFMA4(wc, 0, vc[i], acc_a, acc_a2)
-      }
+      for (int i = 0; i < NL_C; ++i) { BT_MFMA4S(wc4[i], vc[i], acc_a, acc_a2) }
       acc_a += acc_a2;
     }
 
@@ -1052,7 +1116,7 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
     if ((c) == 0) { nap_dh = bt_nap_adjust(nap_dh, wctx.spun); BT_STAMP(12); }                   \
     BT_SB();                                                                                       \
     if (use_rows) {                                                                                \
-      _Pragma("unroll") for (int i = 0; i < BURST; ++i) { BT_MFMA4(aop, i, vdh[BURST * (c) + i], acc_r, acc_r2) } \
+      _Pragma("unroll") for (int i = 0; i < BURST; ++i) { BT_MFMA4F(aop, i, vdh[BURST * (c) + i], acc_r, acc_r2) } \
     }                                                                                              \
     BT_SB();                                                                                       \
   }
@@ -1220,11 +1284,12 @@ int taco_decoder_batch_supported(const taco_dims& d, int n_wg) {
 }
 
 int taco_decoder_batch_prepare(taco_handle h) {
-  const void* k = reinterpret_cast<const void*>(taco_decoder_batch_kernel);
-  TACO_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)taco_decoder_batch_lds_bytes()));
-  int per_cu = 0;
-  TACO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, NT, taco_decoder_batch_lds_bytes()));
-  if (per_cu < 1) TACO_FAIL(TACO_EINVAL, "lockstep decoder kernel does not fit on a CU (occupancy query returned %d)", per_cu);
+  for (const void* k : {reinterpret_cast<const void*>(taco_decoder_batch_kernel<false>), reinterpret_cast<const void*>(taco_decoder_batch_kernel<true>)}) {
+    TACO_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)taco_decoder_batch_lds_bytes()));
+    int per_cu = 0;
+    TACO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, NT, taco_decoder_batch_lds_bytes()));
+    if (per_cu < 1) TACO_FAIL(TACO_EINVAL, "lockstep decoder kernel does not fit on a CU (occupancy query returned %d)", per_cu);
+  }
   return TACO_OK;
 }
 
@@ -1309,7 +1374,8 @@ int taco_launch_decoder_batch(taco_handle h, const float* memory, const float* p
   }
 #endif
   if (group == 0) TACO_HIP(hipEventRecord(h->ev_start, s));
-  hipLaunchKernelGGL(taco_decoder_batch_kernel, dim3(TACO_BT_WGS), dim3(NT), taco_decoder_batch_lds_bytes(), s, a);
+  if (h->bat_bf16) hipLaunchKernelGGL(taco_decoder_batch_kernel<true>, dim3(TACO_BT_WGS), dim3(NT), taco_decoder_batch_lds_bytes(), s, a);
+  else hipLaunchKernelGGL(taco_decoder_batch_kernel<false>, dim3(TACO_BT_WGS), dim3(NT), taco_decoder_batch_lds_bytes(), s, a);
   TACO_HIP(hipGetLastError());
   return TACO_OK;
 }

@@ -131,6 +131,7 @@ struct taco_handle_s {
   taco_bat_layout bat_lay;
   float* bat_wstream;        // attention-LSTM input columns in the lockstep kernel's streaming order
   int bat_ok;                // the lockstep kernel can run this model
+  int bat_bf16;              // its LSTM gate rows are held and multiplied as bf16 (taco_set_precision)
   taco_dec_ctl* dec_ctl;     // device, one block per launch of a taco_decode call (grow-only)
   taco_dec_ctl* dec_ctl_host;  // pinned host mirror
   int dec_ctl_cap;

@@ -157,7 +157,6 @@ __global__ __launch_bounds__(256) void taco_conv_kernel(const float* __restrict_
     // one slab ago) in the other LDS buffer
     auto slab = [&](int s, float (&fw)[NW], float (&fx)[XR][NX], const float (&kw)[NW], const float (&kx)[XR][NX]) {
       const int buf = s & 1;
-      load_slab((sl0 + min(s + 2, n_slabs - 1)) * CI, fw, fx);      // past the end: a harmless reload of the last slab
       // operands of step+1 are read from LDS while the MFMAs of step run (two register sets)
       float av[2][KS], bv[2][KS];
       auto read_operands = [&](int step, int set) {
@@ -171,10 +170,19 @@ __global__ __launch_bounds__(256) void taco_conv_kernel(const float* __restrict_
       read_operands(0, 0);
 #pragma unroll
       for (int step = 0; step < CI / 4; ++step) {
+        // the scheduling barriers keep the reads of step + 1 ahead of the products of step (left to itself the compiler
+        // moves every read down to its use, and each step then waits out the LDS latency with the matrix cores idle)
         if (step + 1 < CI / 4) read_operands(step + 1, (step + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk)
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[step & 1][kk], bv[step & 1][kk], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (step == 0) {
+          // the global loads of slab s + 2 go out behind the first products, not between the barrier and them
+          load_slab((sl0 + min(s + 2, n_slabs - 1)) * CI, fw, fx);      // past the end: a harmless reload of the last slab
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
       store_slab(buf ^ 1, kw, kx);
       __syncthreads();

@@ -201,6 +201,17 @@ class Tacotron2:
       self._frame_clock, ptr, cap = None, C.c_void_p(0), 0
     _lib.check(_lib.lib().taco_set_frame_clock(self._require(), ptr, cap))
 
+  def set_precision(self, precision: str) -> None:
+    """"fp32" (default: every result within the fp32 parity bounds) or "bf16": the decoder of batches keeps the gate
+    rows of its two LSTM cells as bf16 and multiplies them with bf16-rounded activations (fp32 accumulation and
+    cell states).  Faster; frames within 2e-3 of the reference's under teacher forcing, stop frames may differ.
+    The reference has no such switch (it computes in fp32); nothing selects "bf16" unless the caller does."""
+    codes = {"fp32": 0, "bf16": 1}
+    if precision not in codes:
+      raise ValueError(f"precision must be one of {sorted(codes)}, not {precision!r}")
+    _lib.check(_lib.lib().taco_set_precision(self._require(), codes[precision]))
+    self.precision = precision
+
   def frame_latencies_us(self, n_frames: int) -> torch.Tensor:
     """Latency of frames 1 .. n_frames-1 of the last decode's utterance 0 in microseconds (differences of
     consecutive clock readings, 10 ns each), on the host."""

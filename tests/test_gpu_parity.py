@@ -461,6 +461,60 @@ def test_lockstep_teacher_forced_matches_reference(name, monkeypatch):
   np.testing.assert_allclose(align1[0].cpu().numpy(), z["alignments"], atol=TF_TOL, rtol=0)
 
 
+BF16_TOL = 2e-3         # teacher-forced frames of the bf16 setting against the reference's fp32 frames, absolute, log-mel scale
+                        # (measured: 1.9e-4 over the 171 frames of `ljs`, 4.4e-4 over the 1000 of `ljs_1000`)
+
+
+@pytest.mark.parametrize("name", ["ljs", "thchs", "ljs_1000"])
+def test_lockstep_bf16_setting_stays_within_its_stated_tolerance(name, monkeypatch):
+  """The opt-in bf16 setting of the lockstep kernel (gate rows of both LSTM cells and their operands in bf16, fp32
+  accumulation) under teacher forcing against the reference's fp32 frames: mel frames, stop energies and attention
+  weights within 2e-3, everything finite; back on the default setting the fp32 bound holds again."""
+  z, meta = load_golden(name)
+  gm = gpu_model(meta["scenario"], meta["gate"])
+  ck = scenario_checkpoint(meta["scenario"], meta["gate"])
+  ids1 = golden_ids(z)
+  n = meta["n_frames"]
+  T1 = ids1["symbols"].shape[1]
+  lens = [T1, 33, T1, 150]
+  ids = scenarios.random_ids(ck, lens, seed=77)
+  for b in (0, 2):
+    for k in ("symbols", "stresses", "tones", "durations", "speakers"):
+      if ids[k] is not None:
+        ids[k][b, :T1] = ids1[k][0]
+  for b in range(len(lens)):
+    ids["speakers"][b, :] = ids["speakers"][b, 0]
+  masks = prenet_keep_masks(meta["seed"], n, gm.dims.P)
+  lens_d = dev(np.array(lens, np.int32))
+  mem, pm = gm.encode([dev(c) for c in chans(ids)], dev(ids["speakers"]), lens_d)
+  forced = torch.zeros(len(lens), gm.dims.n_mel, n, device="cuda:0")
+  forced[0] = dev(z["mel"])
+  forced[2] = dev(z["mel"])
+  monkeypatch.setenv("TACO_DECODER", "lockstep")
+  thr = meta.get("gate_threshold", 0.5)
+  try:
+    gm.set_precision("bf16")
+    mel, gate, align, nf, _ = gm.decode(mem, pm, lens_d, masks, n, forced_mel=forced, gate_threshold=thr)
+  finally:
+    gm.set_precision("fp32")
+  assert nf.cpu().tolist() == [n] * len(lens)
+  assert bool(torch.isfinite(mel).all()) and bool(torch.isfinite(align).all())
+  err = float(np.abs(mel[0].cpu().numpy() - z["mel"]).max())
+  print(f"bf16 setting, {name}: max |mel - reference| = {err:.2e} over {n} teacher-forced frames")
+  for b in (0, 2):
+    np.testing.assert_allclose(mel[b].cpu().numpy(), z["mel"], atol=BF16_TOL, rtol=0)
+    np.testing.assert_allclose(gate[b].cpu().numpy(), z["gate"], atol=BF16_TOL, rtol=0)
+  assert torch.equal(mel[0], mel[2])           # a slot's result does not depend on its neighbours in this setting either
+  if "alignments" in z:
+    np.testing.assert_allclose(align[0, :, :T1].cpu().numpy(), z["alignments"], atol=BF16_TOL, rtol=0)
+  # the default setting afterwards: fp32 bounds again
+  mel32, _, _, _, _ = gm.decode(mem, pm, lens_d, masks, n, forced_mel=forced, gate_threshold=thr)
+  np.testing.assert_allclose(mel32[0].cpu().numpy(), z["mel"], atol=TF_TOL, rtol=0)
+  assert err > 1e-5, "the bf16 setting should differ measurably from fp32 (is it switched on?)"
+  with pytest.raises(ValueError):
+    gm.set_precision("fp8")
+
+
 def test_lockstep_groups_and_long_lines_mix(gate_table):
   """Seventeen-plus utterances (a full group and a part-filled one) with lines on both sides of the lockstep kernel's
   224-symbol capacity (the long ones run the batch-1 kernel inside the same call), one-symbol lines, a stop on the

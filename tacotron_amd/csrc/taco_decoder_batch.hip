@@ -493,6 +493,30 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
       lds[LP_W1 + e] = (r < P && k < NMEL) ? a.prenet_w1[(size_t)r * NMEL + k] : 0.0f;
     }
   }
+  if constexpr (BF) {
+    // P: the folded layer-1 rows and the layer-2 rows become bf16 A operands of 16-deep steps, [load][lane] x 8 bytes,
+    // in place over their fp32 copies (a load = 4 k-steps; the bf16 copy of loads 0 .. L ends before the fp32 words of
+    // load L + 1 begin).  The projection / stop-token rows of the M workgroups stay fp32: they make the frame itself.
+    if (is_p) {
+      auto to_bf16 = [&](int base, int n_loads) {
+        u32x2* out = reinterpret_cast<u32x2*>(lds + base);
+        _Pragma("unroll 1") for (int e0 = 0; e0 < n_loads * 64; e0 += NT) {
+          const int e = e0 + tid;
+          float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+          if (e < n_loads * 64) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = lds[base + ((e >> 6) * 4 + q) * 64 + (e & 63)];
+          }
+          __syncthreads();       // all four words of every element of this pass are read before one is overwritten
+          if (e < n_loads * 64) out[e] = __builtin_bit_cast(u32x2, bt_pack(v[0], v[1], v[2], v[3]));
+          __syncthreads();
+        }
+      };
+      __syncthreads();
+      to_bf16(LP_WF, KS_HC / 4);
+      to_bf16(LP_W2, KP / 16);
+    }
+  }
   float vq[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   if (is_q) {
     _Pragma("unroll 1") for (int e = tid; e < q_cnt * Ra; e += NT) {
@@ -622,6 +646,14 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
   const unsigned w_lane_dh = (unsigned)(a.lay.dh + rep * a.lay.dh_cap) + bt_word(16 * (wave * NL_H) + 4 * kq, utt);
   const unsigned w_lane_c = (unsigned)(a.lay.ctx + rep * a.lay.ctx_cap) + bt_word(16 * (wave * NL_C) + 4 * kq, utt);
   const float4* ws_lane = a.wstream + ((size_t)(j * NW + wave) * (NL_P + NL_C)) * 64 + lane;   // load i: ws_lane[i * 64]
+  // (BF: the attention LSTM's prenet and context columns fit the registers too - 26 per lane - and are not streamed)
+  s16x4 wa_p[BF ? NL_P : 1], wa_c[BF ? NL_C : 1];
+  if constexpr (BF) {
+#pragma unroll
+    for (int i = 0; i < NL_P; ++i) { const float4 w = ws_lane[i * 64]; wa_p[i] = bt_pack(w.x, w.y, w.z, w.w); }
+#pragma unroll
+    for (int i = 0; i < NL_C; ++i) { const float4 w = ws_lane[(NL_P + i) * 64]; wa_c[i] = bt_pack(w.x, w.y, w.z, w.w); }
+  }
   unsigned keep_next = 0;                      // P, wave 0: keep bytes of my 4 rows, layer 0 (low) / layer 1 of the coming frame
   unsigned keep_l1 = 0, keep_l2 = 0;
   if (is_p && wave == 0) {
@@ -658,15 +690,25 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
         const float* w2 = lds + BT_OPQ(LP_W2 + wave * (4 * NL_P) * 64 + lane_f);
         bt_nap_begin(nap_h1, wctx);
         bt_issue<NL_P>(rs, par + w_lane_h1, v);
-        float aop[4 * NL_P];
+        float aop[BF ? 1 : 4 * NL_P];
+        u32x2 aoph[BF ? NL_P : 1];
+        if constexpr (BF) {
+          const u32x2* w2h = reinterpret_cast<const u32x2*>(lds + LP_W2) + BT_OPQ(wave * NL_P * 64 + lane_f);
 #pragma unroll
-        for (int i = 0; i < 4 * NL_P; ++i) aop[i] = w2[i * 64];
+          for (int i = 0; i < NL_P; ++i) aoph[i] = w2h[i * 64];
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4 * NL_P; ++i) aop[i] = w2[i * 64];
+        }
         bt_check<NL_P, 0, NL_P>(rs, par + w_lane_h1, tag, v, wctx, 0x300u);
         nap_h1 = bt_nap_adjust(nap_h1, wctx.spun);
         BT_SB();
         f32x4 acc2 = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int i = 0; i < NL_P; ++i) { BT_MFMA4F(aop, i, v[i], acc, acc2) }
+        for (int i = 0; i < NL_P; ++i) {
+          if constexpr (BF) { acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, aoph[i]), bt_pack(v[i]), acc, 0, 0, 0); }
+          else { BT_MFMA4F(aop, i, v[i], acc, acc2) }
+        }
         acc += acc2;
       }
       acc = bt_reduce_tiles(lds, LP_RED, acc, wave, lane_f);
@@ -751,9 +793,11 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
     // ============ attention LSTM ============
     {
       u32x4 v[NL_P];
-      float4 wp4[NL_P];
+      float4 wp4[BF ? 1 : NL_P];
+      if constexpr (!BF) {
 #pragma unroll
-      for (int i = 0; i < NL_P; ++i) wp4[i] = ws_lane[i * 64];         // my rows' prenet columns (L2), beside the wait below
+        for (int i = 0; i < NL_P; ++i) wp4[i] = ws_lane[i * 64];       // my rows' prenet columns (L2), beside the wait below
+      }
       bt_nap_begin(nap_p, wctx);
       bt_issue<NL_P>(rs, par + w_lane_p, v);
       bt_check<NL_P, 0, NL_P>(rs, par + w_lane_p, tag, v, wctx, 0x400u);
@@ -767,7 +811,10 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
       BT_STAMP(2);
       f32x4 acc2 = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-      for (int i = 0; i < NL_P; ++i) { BT_MFMA4S(wp4[i], v[i], acc_a, acc2) }
+      for (int i = 0; i < NL_P; ++i) {
+        if constexpr (BF) { acc_a = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wa_p[i], bt_pack(v[i]), acc_a, 0, 0, 0); }
+        else { BT_MFMA4S(wp4[i], v[i], acc_a, acc2) }
+      }
       acc_a += acc2;
       const f32x4 pre = bt_reduce_tiles(lds, L_RED, acc_a, wave, lane_f);
       if (wave == 0) {
@@ -1073,11 +1120,23 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
       }
       BT_STAMP(11);
       BT_SB();
-      float4 wc4[NL_C];
+      float4 wc4[BF ? 1 : NL_C];
+      if constexpr (!BF) {
 #pragma unroll
-      for (int i = 0; i < NL_C; ++i) wc4[i] = ws_lane[(NL_P + i) * 64];   // my attention-LSTM rows' context columns (L2)
+        for (int i = 0; i < NL_C; ++i) wc4[i] = ws_lane[(NL_P + i) * 64];   // my attention-LSTM rows' context columns (L2)
+      }
       // while the decoder hidden state travels: the context columns of the P / M rows ...
-      if ((is_p && !forced) || is_m) {
+      if (BF && is_p) {
+        if (!forced) {
+          const u32x2* crow = reinterpret_cast<const u32x2*>(lds + LP_WF) + BT_OPQ((KH / 16 + wave * NL_C) * 64 + lane_f);
+#pragma unroll
+          for (int i = 0; i < NL_C; ++i) {
+            const s16x4 aoph = __builtin_bit_cast(s16x4, crow[i * 64]);
+            if (i & 1) acc_r2 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(aoph, bt_pack(vc[i]), acc_r2, 0, 0, 0);
+            else acc_r = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(aoph, bt_pack(vc[i]), acc_r, 0, 0, 0);
+          }
+        }
+      } else if ((is_p && !forced) || is_m) {
         const float* crow = lds + BT_OPQ((is_p ? LP_WF : LM_W) + (KH / 4 + wave * 4 * NL_C) * 64 + lane_f);
 #pragma unroll
         for (int i = 0; i < NL_C; ++i) {
@@ -1091,7 +1150,12 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
       acc_a = acc_an;
       f32x4 acc_a2 = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-      for (int i = 0; i < NL_C; ++i) { BT_MFMA4S(wc4[i], vc[i], acc_a, acc_a2) }
+      for (int i = 0; i < NL_C; ++i) {
+        if constexpr (BF) {
+          if (i & 1) acc_a2 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wa_c[i], bt_pack(vc[i]), acc_a2, 0, 0, 0);
+          else acc_a = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wa_c[i], bt_pack(vc[i]), acc_a, 0, 0, 0);
+        } else { BT_MFMA4S(wc4[i], vc[i], acc_a, acc_a2) }
+      }
       acc_a += acc_a2;
     }
 
@@ -1105,18 +1169,32 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
         // these rows are what other workgroups wait for: they come first, on operands that stay in registers for the
         // recurrent products afterwards
         const float* rows = lds + BT_OPQ((is_p ? LP_WF : LM_W) + (wave * 4 * NL_H) * 64 + lane_f);
+        const u32x2* rows_h = reinterpret_cast<const u32x2*>(lds + LP_WF) + BT_OPQ(wave * NL_H * 64 + lane_f);   // BF, P only
         const bool use_rows = is_m || !forced;
+        const bool rows_bf = BF && is_p;
 #define BT_ROWS_BURST(c)                                                                           \
   {                                                                                                \
     float aop[4 * BURST];                                                                          \
+    u32x2 aoph[BURST];                                                                             \
     if (use_rows) {                                                                                \
-      _Pragma("unroll") for (int i = 0; i < 4 * BURST; ++i) aop[i] = rows[(4 * BURST * (c) + i) * 64]; \
+      if (rows_bf) {                                                                               \
+        _Pragma("unroll") for (int i = 0; i < BURST; ++i) aoph[i] = rows_h[(BURST * (c) + i) * 64]; \
+      } else {                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < 4 * BURST; ++i) aop[i] = rows[(4 * BURST * (c) + i) * 64]; \
+      }                                                                                            \
     }                                                                                              \
     bt_check<NL_H, BURST * (c), BURST>(rs, par + w_lane_dh, tag, vdh, wctx, 0x900u);                \
     if ((c) == 0) { nap_dh = bt_nap_adjust(nap_dh, wctx.spun); BT_STAMP(12); }                   \
     BT_SB();                                                                                       \
     if (use_rows) {                                                                                \
-      _Pragma("unroll") for (int i = 0; i < BURST; ++i) { BT_MFMA4F(aop, i, vdh[BURST * (c) + i], acc_r, acc_r2) } \
+      if (rows_bf) {                                                                               \
+        _Pragma("unroll") for (int i = 0; i < BURST; ++i) {                                        \
+          if (i & 1) acc_r2 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, aoph[i]), bt_pack(vdh[BURST * (c) + i]), acc_r2, 0, 0, 0); \
+          else acc_r = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, aoph[i]), bt_pack(vdh[BURST * (c) + i]), acc_r, 0, 0, 0); \
+        }                                                                                          \
+      } else {                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < BURST; ++i) { BT_MFMA4F(aop, i, vdh[BURST * (c) + i], acc_r, acc_r2) } \
+      }                                                                                            \
     }                                                                                              \
     BT_SB();                                                                                       \
   }

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Soak run of the decoder's hand-off protocol: many launches over several input lengths, every
 launch compared bit for bit with the first one of its length (a lost or stale hand-off word would
-change frames or end in the kernel's give-up path).  Usage: soak.py [launches per length] [frames]"""
+change frames or end in the kernel's give-up path).  Usage: soak.py [launches per length] [frames]
+TACO_PRECISION=bf16 runs the lockstep part in the bf16 setting."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -28,9 +29,18 @@ for T_in in (1, 30, 102, 256, 300, 512):
       bad += 1
       print(f"T_in={T_in} encode {i}: output differs from the first call", flush=True)
   first = None
+  post0 = None
   t0 = time.perf_counter()
   for i in range(n):
     mel, gate, align, nf, reached = m.decode(mem, pm, None, masks, frames, gate_threshold=2.0)
+    # the convolutions whose tiles several workgroups share meet their partial tiles through a counter: same check
+    pcols = min(250, frames)
+    post = m.postnet(mel[:, :, :pcols].contiguous(), torch.full((1,), pcols, dtype=torch.int32, device="cuda:0"))
+    if post0 is None:
+      post0 = post.clone()
+    elif not torch.equal(post, post0):
+      bad += 1
+      print(f"T_in={T_in} postnet {i}: output differs from the first call", flush=True)
     if first is None:
       first = (mel.clone(), gate.clone(), align.clone())
       assert int(nf[0]) == frames and bool(torch.isfinite(mel).all())
@@ -45,6 +55,8 @@ gate = __import__("json").load(open(os.path.join(os.path.dirname(os.path.dirname
 ckpt = scenarios.checkpoint("ljs", gate)
 hp = get_hparams(ckpt)
 m = Tacotron2(hp, **abi.mapping_counts(ckpt, hp)); m.load_state_dict(ckpt["model_state"]); m.to("cuda:0")
+if os.environ.get("TACO_PRECISION"):
+  m.set_precision(os.environ["TACO_PRECISION"])
 for B, steps in ((64, 400), (17, 150), (200, 250)):
   lens = np.random.RandomState(B).randint(3, 209, size=B).tolist()
   ids = scenarios.random_ids(ckpt, lens, seed=B)

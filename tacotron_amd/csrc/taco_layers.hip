@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void taco_conv_kernel(const float* __restrict_
   const int ksl = split > 1 ? blockIdx.x % split : 0;
   const int t0 = tile_t * CV_TT;
   const int co0 = blockIdx.y * CV_CO;
-  const int len = lens ? lens[b] : T;
+  const int len = lens ? min(lens[b], T) : T;      // (a length beyond the buffers' T columns is read as T)
   const float* in_b = in + (size_t)b * c_in * T;
   taco_f32x16 acc;
 #pragma unroll

@@ -59,7 +59,8 @@ if wc:
   for k in ("SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_SCA", "SQ_WAIT_INST_ANY"):
     if k in c:
       d[k + "_per_WAVE_CYCLE"] = round(c[k] / wc, 4)
-for k in ("SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_INSTS_VALU_MFMA_F32", "SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_INSTS_LDS", "SQ_INSTS_SALU",
+for k in ("SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_INSTS_VALU_MFMA_F32", "SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_INSTS_VALU_MFMA_BF16",
+          "SQ_INSTS_VALU_MFMA_MOPS_BF16", "SQ_INSTS_LDS", "SQ_INSTS_SALU",
           "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"):
   if k in c:
     d[k + "_per_lockstep_frame"] = round(c[k] / FRAMES, 1)
@@ -68,14 +69,16 @@ if kernel_ns and "SQ_VALU_MFMA_BUSY_CYCLES" in c:
   # all 1024 SIMDs for its whole duration at the shader clock (2.4 GHz)
   cycles_available = kernel_ns * 2.4 * SIMDS
   d["mfma_busy_share_of_simd_cycles"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / cycles_available, 4)
-  d["mfma_busy_cycles_per_mfma_instruction"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / max(c.get("SQ_INSTS_VALU_MFMA_F32", c.get("SQ_INSTS_MFMA", 1)), 1), 2)
+  n_mfma = c.get("SQ_INSTS_VALU_MFMA_F32", 0) + c.get("SQ_INSTS_VALU_MFMA_BF16", 0) or c.get("SQ_INSTS_MFMA", 1)
+  d["mfma_busy_cycles_per_mfma_instruction"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / max(n_mfma, 1), 2)
 if "SQ_LDS_IDX_ACTIVE" in c:
   d["lds_bank_conflict_cycles_per_active_cycle"] = round(c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"], 4)
 if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
   d["hbm_bytes_per_lockstep_frame"] = int(round((2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 / FRAMES))
   d["traffic_correction"] = "FETCH_SIZE x2 (gfx950 reports half), WRITE_SIZE as reported, KiB units, separate passes"
 (dst / f"{tag}_lockstep_pmc.json").write_text(json.dumps({
-  "kernel": KERNEL, "workload": "64 lines of 40..160 symbols, 600 frames each: one dispatch, 16 utterances in flight, slots refilled",
+  "kernel": KERNEL, "precision": __import__("os").environ.get("TACO_PRECISION", "fp32"),
+  "workload": "64 lines of 40..160 symbols, 600 frames each: one dispatch, 16 utterances in flight, slots refilled",
   "lockstep_frames_per_dispatch": FRAMES, "kernel_avg_ns": kernel_ns,
   "per_dispatch": {k: round(v, 1) for k, v in sorted(c.items())}, "derived": d,
   "command": "rocprofv3 --pmc <one block-limited set per pass> -- python3 scripts/batch_once.py 64 600 1 (scripts/profile_lockstep.sh)",

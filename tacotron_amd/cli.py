@@ -40,7 +40,8 @@ from tacotron_amd.config import parse_hparams_string
 
 DEFAULT_MAX_DECODER_STEPS = 3000     # reference: src/tacotron_cli/defaults.py
 DEFAULT_DEVICE = "cuda:0"
-WRITE_BEHIND = 16                     # lines whose files may still be on their way to the disk
+WRITE_BEHIND = 16                     # lines whose files may still be on their way to the disk (batch mode: one batch's worth)
+WRITERS = 2                           # threads writing them (numpy releases the interpreter lock while it writes)
 
 Utterances = "OrderedDict[int, List[str]]"
 Paragraphs = "OrderedDict[int, OrderedDict[int, List[str]]]"
@@ -174,8 +175,9 @@ def synthesize_plan(synth, plan: Sequence[PlannedLine], speaker: Optional[str], 
   costs = [sharding.predicted_cost(len(item.symbols)) for item in plan]
 
   def work(indices: List[int]) -> Dict[int, Dict[str, object]]:
-    # The files of one line are written by a single background thread while the GPU works on the next
-    # line; at most WRITE_BEHIND lines wait for the disk, and a failed write surfaces at its own line.
+    # The files of a line are written by background threads while the GPU works on the next line (or batch);
+    # at most WRITE_BEHIND lines (a batch's worth in batch mode, so that one batch is written while the next
+    # is decoded) wait for the disk, and a failed write surfaces at its own line.
     pending: "collections.deque" = collections.deque()
     out: Dict[int, Dict[str, object]] = {}
 
@@ -185,7 +187,7 @@ def synthesize_plan(synth, plan: Sequence[PlannedLine], speaker: Optional[str], 
         out[i] = future.result()
 
     groups = list(sharding.batches(indices, batch_size))
-    with concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="taco-write") as writer, \
+    with concurrent.futures.ThreadPoolExecutor(max_workers=WRITERS, thread_name_prefix="taco-write") as writer, \
          concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="taco-prep") as prep:
       # In batch mode the next batch's symbols are mapped to ids on a second thread while the GPU decodes the
       # current one (the library call releases the interpreter lock for as long as the decoder runs).
@@ -204,7 +206,7 @@ def synthesize_plan(synth, plan: Sequence[PlannedLine], speaker: Optional[str], 
                                       seed=seed, include_stats=include_stats, **({} if prepared is None else {"prepared": prepared}))
         for i, res in zip(group_idx, results):
           pending.append((i, writer.submit(_write_line, plan[i], res, include_stats)))
-        settle(WRITE_BEHIND)
+        settle(max(WRITE_BEHIND, batch_size))
       settle(0)
     return out
 

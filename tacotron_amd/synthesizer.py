@@ -55,9 +55,12 @@ def init_global_seeds(seed: int) -> None:
   os.environ["PYTHONHASHSEED"] = str(seed)
   random.seed(seed)
   np.random.seed(seed)
-  torch.manual_seed(seed)
+  # torch.manual_seed(seed) = the CPU generator + every accelerator back-end torch knows; for the back-ends this
+  # machine does not have it queues a deferred call together with a formatted stack trace (10 ms per call, and the
+  # queue grows with every line synthesized), so the two generators that exist are seeded directly
+  torch.default_generator.manual_seed(int(seed))
   if torch.cuda.is_available():
-    torch.cuda.manual_seed(seed)
+    torch.cuda.manual_seed_all(int(seed))
 
 
 def spectrogram_duration_s(n_frames: int, n_fft: int, hop_length: int, sr: int = 22050) -> float:

@@ -369,8 +369,9 @@ def main():
                  "parallelism": f"{world} rank(s), one full model replica each, utterance-sharded, host-side gather only"},
       "real_time_factor": round(args.steps * audio_s / elapsed, 1),
       "rank0_frames_per_s": round(my_frames / float(np.mean(rank_s)), 1),
-      "note": "one GPU runs workload b1 by default (batch-1 latency, BASELINE configs[1]); `--workload lines` gives the one-GPU "
-              "figure of this workload",
+      "per_gpu_frames_per_s": round(value / world, 1),
+      "note": "one GPU runs workload b1 by default (batch-1 latency, BASELINE configs[1]); the one-GPU figure of THIS workload is "
+              "`lines_one_gpu.value` of that run's line (= `--workload lines`): weak-scaling efficiency = value / (n_gpus x that)",
     }
     # the dominant kernel's roofline: measured on this rank's GPU outside the timed region (every rank does the same
     # work, rank 0's figures are printed); the CPU baseline belongs to the one-GPU run of workload b1
@@ -478,6 +479,19 @@ def main():
   if rank == 0 and world == 1:
     out["batch64"] = batch64_record(model, ckpt, device)
     out["batch64_bf16"] = batch64_bf16_record(model, ckpt, device, out["batch64"])
+    # the workload `--gpus N` runs for N > 1, on this one GPU: the figure a whole-node value is to be compared with
+    # (N x this = ideal weak scaling; every rank of an N-GPU run decodes the same number of lines as this run does)
+    lstep, _, ljob, ldesc = lines_workload(model, ckpt, device, 1, 0, args.lines_per_gpu, frames, args.batch_size)
+    lstep()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(3):
+      lstep()
+    torch.cuda.synchronize(device)
+    lsec = (time.perf_counter() - t0) / 3
+    out["lines_one_gpu"] = {"workload": ldesc, "value": round(ljob / lsec, 1), "unit": "mel frames/s",
+                            "ms_per_step": round(lsec * 1e3, 3), "steps": 3,
+                            "note": "same as `python bench.py --workload lines`; runs with --gpus N > 1 measure this workload"}
   if rank == 0 and world == 1 and args.cpu_seconds > 0:
     out["cpu_baseline"] = cpu_baseline(ckpt, sym, st, spk, args.cpu_seconds)
     try:

@@ -1066,7 +1066,6 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
       if (is_q) {
         // Q: the other half of the attention hidden state (see above); the context loads go out before its last products
         u32x4 vah[NL_H / 2];
-        f32x4 acc_an2 = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int i = 0; i < NL_H / 2; ++i) vah[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (par + w_lane_ah + 256u * (NL_H / 2 + i)) * 4u, 0, 16);
         BT_SB();

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void taco_embed_kernel(const EmbedArgs a) {
 constexpr int CV_CO = 32, CV_TT = 64, CV_XS = 96;
 constexpr int taco_conv_ci(int ks) { return ks == 1 ? 64 : 32; }
 constexpr size_t taco_conv_lds_bytes(int ks) {
-  return sizeof(float) * 2 * ((size_t)taco_conv_ci(ks) * CV_XS + (size_t)CV_CO * (taco_conv_ci(ks) * ks + 1));
+  return sizeof(float) * 2 * ((size_t)taco_conv_ci(ks) * CV_XS + (size_t)CV_CO * (taco_conv_ci(ks) * ks + 2));
 }
 typedef float taco_f32x16 __attribute__((ext_vector_type(16)));
 
@@ -76,18 +76,20 @@ __global__ __launch_bounds__(256) void taco_conv_kernel(const float* __restrict_
                                                         const float* __restrict__ alpha, const float* __restrict__ beta,
                                                         const float* __restrict__ residual, const int32_t* lens,
                                                         int c_in, int c_out, int T, int act, int layout,
-                                                        const float* __restrict__ zero_word, int split, float* split_ws) {
+                                                        int split, float* split_ws) {
   constexpr bool in_time_major = IN_TM;          // input is [T][C] instead of [C][T]
   const bool out_time_major = layout & 2;        // output likewise
   constexpr int CI = taco_conv_ci(KS);         // input channels per slab
   constexpr int PAD = (KS - 1) / 2;
   constexpr int XW = CV_TT + KS - 1;           // input columns a tile needs
   constexpr int XS = CV_XS;                    // row stride = 32 (mod 64): the two k-lanes of an MFMA hit disjoint banks
-  constexpr int WS = CI * KS + 1;              // odd row stride: 32 rows -> 32 banks
+  constexpr int WS = CI * KS + 2;              // row stride = 2 or 34 (mod 64): the 32 rows of a k-lane fall on the 32 even banks, the
+                                               // other k-lane's (an odd number of floats further) on the odd ones; even, so that a
+                                               // thread's staged weights go to LDS as 8-byte writes
   constexpr int RL = CI * KS;                  // weights of one output channel in a slab: contiguous in memory
   constexpr int NW = RL / 8;                   // 8 threads per weight row, NW consecutive floats each
   constexpr int NX = (XW + 7) / 8;             // 8 threads per input row, columns seg, seg + 8, ...
-  static_assert(XW <= XS && 2 * CV_CO * WS >= 2 * 16 * 64 && RL % 32 == 0 && CI * 8 == 256 * (CI / 32), "tile geometry");
+  static_assert(XW <= XS && 2 * CV_CO * WS >= 2 * 16 * 64 && RL % 32 == 0 && CI * 8 == 256 * (CI / 32) && NW % 2 == 0 && (2 * CI * XS) % 2 == 0, "tile geometry");
   extern __shared__ __attribute__((aligned(16))) float conv_lds[];
   float (*xs)[CI][XS] = reinterpret_cast<float (*)[CI][XS]>(conv_lds);                       // [2][CI][XS]
   float (*ws)[CV_CO][WS] = reinterpret_cast<float (*)[CV_CO][WS]>(conv_lds + 2 * CI * XS);   // [2][CV_CO][WS]
@@ -108,93 +110,106 @@ __global__ __launch_bounds__(256) void taco_conv_kernel(const float* __restrict_
   for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 
   if (t0 < len) {
-    // Staging map (all address arithmetic outside the slab loop): thread = (row tid >> 3, segment tid & 7).
-    // Weights: row = output channel, the thread takes NW consecutive floats of the slab's RL.  Inputs: CI / 32
-    // rows per thread (row + 32 q), columns seg + 8 n.
+    // Staging map: thread = (row tid >> 3, segment tid & 7).  Weights: row = output channel, the thread takes NW
+    // consecutive floats of the slab's RL (16-byte loads).  Inputs: CI / 32 rows per thread (row + 32 q), columns
+    // seg + 8 n.  Both come through buffer loads, whose out-of-range offsets return zero: a padding position, a column
+    // past the utterance, an input channel past c_in or a weight row past c_out is simply given the offset ~0 (no
+    // branch, no 64-bit address arithmetic, nothing read that is not there).  A ragged last slab's weight loads run on
+    // into the next row's weights - finite values that meet input rows staged as zeros.
     constexpr int XR = CI / 32;
-    typedef float taco_f4u __attribute__((ext_vector_type(4), aligned(4)));
+    constexpr int LW = NW / 4, LX = XR * NX;     // load items of a slab per thread: 16-byte weight loads, input words
+    constexpr int SW = NW / 2, SX = XR * NX;     // store items: 8-byte weight writes, input words
+    constexpr int ITEMS = LW + LX + SW + SX;
+    constexpr int MFMAS = KS * (CI / 4);         // matrix-core products of a slab per wave
+    constexpr unsigned OOB = 0xffffffffu;
+    typedef unsigned taco_u4 __attribute__((ext_vector_type(4)));
     const int srow = tid >> 3, seg = tid & 7;
-    const bool w_row_ok = co0 + srow < c_out;
-    const float* w_row = w + (size_t)(w_row_ok ? co0 + srow : 0) * c_in * KS + seg * NW;
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, (int)((unsigned)c_out * (unsigned)c_in * KS * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)in_b, 0, (int)((unsigned)c_in * (unsigned)T * 4u), 0x00020000);
+    const unsigned w_off = co0 + srow < c_out ? ((unsigned)(co0 + srow) * (unsigned)c_in * KS + (unsigned)(seg * NW)) * 4u : OOB;
+    unsigned col_off[NX];                        // byte offset of my column n inside a row (channel-major) / of its row (position-major)
+#pragma unroll
+    for (int n = 0; n < NX; ++n) {
+      const int c = seg + 8 * n, tt = t0 + c - PAD;
+      col_off[n] = (c < XW && tt >= 0 && tt < len) ? (unsigned)tt * (in_time_major ? (unsigned)c_in : 1u) * 4u : OOB;
+    }
     float pwA[NW], pxA[XR][NX], pwB[NW], pxB[XR][NX];
-    auto load_slab = [&](int ci0, float (&pw)[NW], float (&px)[XR][NX]) {
-      // Unconditional 16-byte loads keep the slab loop free of branches.  In a ragged last slab (and in rows
-      // past c_out, which are clamped to row 0 and never stored) they run on into the following weights: finite
-      // values that meet input rows staged as zeros, so they add nothing.
-      const float* src = w_row + (size_t)ci0 * KS;
-#pragma unroll
-      for (int n = 0; n < NW; n += 4) {
-        const taco_f4u v = *reinterpret_cast<const taco_f4u*>(src + n);
-        pw[n] = v.x; pw[n + 1] = v.y; pw[n + 2] = v.z; pw[n + 3] = v.w;
-      }
-#pragma unroll
-      for (int q = 0; q < XR; ++q) {
+    // item `it` of the loads of the slab that starts at input channel ci0
+    auto load_item = [&](int it, int ci0, float (&pw)[NW], float (&px)[XR][NX]) {
+      if (it < LW) {
+        const unsigned off = w_off == OOB ? OOB : w_off + (unsigned)(ci0 * KS + 4 * it) * 4u;
+        const taco_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_w, off, 0, 0);
+        pw[4 * it] = __uint_as_float(v.x); pw[4 * it + 1] = __uint_as_float(v.y);
+        pw[4 * it + 2] = __uint_as_float(v.z); pw[4 * it + 3] = __uint_as_float(v.w);
+      } else {
+        const int q = (it - LW) / NX, n = (it - LW) % NX;
         const int ci = ci0 + srow + 32 * q;
-#pragma unroll
-        for (int n = 0; n < NX; ++n) {
-          const int c = seg + 8 * n;
-          const int tt = t0 + c - PAD;
-          const bool ok = c < XW && ci < c_in && tt >= 0 && tt < len;
-          const size_t at = in_time_major ? (size_t)tt * c_in + ci : (size_t)ci * T + tt;
-          px[q][n] = *(ok ? in_b + at : zero_word);    // padding reads a zero word in global memory: one plain
-                                                       // global load, nothing to wait for here
-        }
+        const unsigned row = (unsigned)ci * (in_time_major ? 1u : (unsigned)T) * 4u;
+        const unsigned off = (col_off[n] != OOB && ci < c_in) ? col_off[n] + row : OOB;
+        px[q][n] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_x, off, 0, 0));
       }
     };
-    auto store_slab = [&](int buf, const float (&pw)[NW], const float (&px)[XR][NX]) {
-#pragma unroll
-      for (int n = 0; n < NW; ++n) ws[buf][srow][seg * NW + n] = pw[n];
-#pragma unroll
-      for (int q = 0; q < XR; ++q)
-#pragma unroll
-        for (int n = 0; n < NX; ++n)
-          if (seg + 8 * n < XW) xs[buf][srow + 32 * q][seg + 8 * n] = px[q][n];
+    auto store_item = [&](int it, int buf, const float (&pw)[NW], const float (&px)[XR][NX]) {
+      if (it < SW) {
+        *reinterpret_cast<float2*>(&ws[buf][srow][seg * NW + 2 * it]) = make_float2(pw[2 * it], pw[2 * it + 1]);
+      } else {
+        const int q = (it - SW) / NX, n = (it - SW) % NX;
+        if (seg + 8 * n < XW) xs[buf][srow + 32 * q][seg + 8 * n] = px[q][n];
+      }
     };
     const int n_slabs_all = (c_in + CI - 1) / CI;
     const int sl0 = ksl * n_slabs_all / split;                     // my slabs: sl0 .. sl0 + n_slabs - 1 (at least one)
     const int n_slabs = (ksl + 1) * n_slabs_all / split - sl0;
-    // one slab: fetch slab s+2 into `fetch`, multiply slab s (LDS buffer s&1), park slab s+1 (`park`, fetched
-    // one slab ago) in the other LDS buffer
+    // One slab: multiply slab s (LDS buffer s & 1), fetch slab s + 2 into `fetch`, park slab s + 1 (`park`, fetched one
+    // slab ago) in the other LDS buffer.  A wave's products form one dependent chain (a product issues when the one
+    // before has left the matrix core, 64 cycles), and a wave issues in order: whatever stands between two products
+    // runs in the first one's shadow, whatever is bunched up behind the last one does not.  So the slab's staging work
+    // - the operand reads of the next step, the global loads, the LDS writes - is dealt out one or two instructions at
+    // a time behind each product, and scheduling barriers keep the compiler from gathering it up again.
     auto slab = [&](int s, float (&fw)[NW], float (&fx)[XR][NX], const float (&kw)[NW], const float (&kx)[XR][NX]) {
       const int buf = s & 1;
-      // operands of step+1 are read from LDS while the MFMAs of step run (two register sets)
+      const int ci_next = (sl0 + min(s + 2, n_slabs - 1)) * CI;     // past the end: a harmless reload of the last slab
       float av[2][KS], bv[2][KS];
-      auto read_operands = [&](int step, int set) {
+      auto read_pair = [&](int step, int set, int kk) {
         const int cl = khalf * (CI / 2) + step * 2 + h;    // this lane's input channel of the k-pair
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk) {
-          av[set][kk] = ws[buf][i][cl * KS + kk];
-          bv[set][kk] = xs[buf][cl][thalf * 32 + i + kk];
-        }
+        av[set][kk] = ws[buf][i][cl * KS + kk];
+        bv[set][kk] = xs[buf][cl][thalf * 32 + i + kk];
       };
-      read_operands(0, 0);
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) read_pair(0, 0, kk);
 #pragma unroll
       for (int step = 0; step < CI / 4; ++step) {
-        // the scheduling barriers keep the reads of step + 1 ahead of the products of step (left to itself the compiler
-        // moves every read down to its use, and each step then waits out the LDS latency with the matrix cores idle)
-        if (step + 1 < CI / 4) read_operands(step + 1, (step + 1) & 1);
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk)
+        for (int kk = 0; kk < KS; ++kk) {
+          const int m = step * KS + kk;
+          if (step + 1 < CI / 4) read_pair(step + 1, (step + 1) & 1, kk);
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[step & 1][kk], bv[step & 1][kk], acc, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (step == 0) {
-          // the global loads of slab s + 2 go out behind the first products, not between the barrier and them
-          load_slab((sl0 + min(s + 2, n_slabs - 1)) * CI, fw, fx);      // past the end: a harmless reload of the last slab
+#pragma unroll
+          for (int it = m * ITEMS / MFMAS; it < (m + 1) * ITEMS / MFMAS; ++it) {
+            if (it < LW + LX) load_item(it, ci_next, fw, fx);
+            else store_item(it - (LW + LX), buf ^ 1, kw, kx);
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      store_slab(buf ^ 1, kw, kx);
       __syncthreads();
     };
-    load_slab(sl0 * CI, pwA, pxA);
-    load_slab((sl0 + min(1, n_slabs - 1)) * CI, pwB, pxB);
-    store_slab(0, pwA, pxA);
+#pragma unroll
+    for (int it = 0; it < LW + LX; ++it) load_item(it, sl0 * CI, pwA, pxA);
+#pragma unroll
+    for (int it = 0; it < LW + LX; ++it) load_item(it, (sl0 + min(1, n_slabs - 1)) * CI, pwB, pxB);
+#pragma unroll
+    for (int it = 0; it < SW + SX; ++it) store_item(it, 0, pwA, pxA);
     __syncthreads();
-    for (int s = 0; s < n_slabs; s += 2) {
+    // (Both slabs of a pair unconditionally inside the loop, the odd one behind it: with `if (s + 1 < n_slabs)` around
+    // the second, the compiler sees a path from the first slab straight back to the loop's top on which the first
+    // slab's loads are still in flight, and drains every load at the top of each pair.)
+    int s = 0;
+    for (; s + 1 < n_slabs; s += 2) {
       slab(s, pwA, pxA, pwB, pxB);
-      if (s + 1 < n_slabs) slab(s + 1, pwB, pxB, pwA, pxA);
+      slab(s + 1, pwB, pxB, pwA, pxA);
     }
+    if (s < n_slabs) slab(s, pwA, pxA, pwB, pxB);
     // add the two channel halves: waves 2, 3 hand their tiles to waves 0, 1 through LDS
     float* red = &ws[0][0][0];     // 2 x 16 x 64 floats fit the weight buffers
     if (khalf == 1) {
@@ -486,17 +501,7 @@ int taco_launch_embed(taco_handle h, const int64_t* const* ids_dev, const int32_
   return TACO_OK;
 }
 
-// One zero word per device in global memory: what staging loads of padding positions read.
-static float* g_conv_zero[64] = {nullptr};
-
 int taco_conv_prepare() {
-  int dev = 0;
-  TACO_HIP(hipGetDevice(&dev));
-  if (dev < 0 || dev >= 64) TACO_FAIL(TACO_EINVAL, "device index %d", dev);
-  if (!g_conv_zero[dev]) {
-    TACO_HIP(hipMalloc((void**)&g_conv_zero[dev], 256));
-    TACO_HIP(hipMemset(g_conv_zero[dev], 0, 256));
-  }
   // the slab buffers exceed the default 64 KiB of dynamic LDS for the wider kernels
 #define TACO_CONV_ATTR(KS)                                                                                      \
   TACO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(taco_conv_kernel<KS, false>), hipFuncAttributeMaxDynamicSharedMemorySize, \
@@ -530,10 +535,9 @@ static int taco_conv_split_factor(int base_tiles, int n_slabs, int n_cu) {
 int taco_launch_conv(const float* in, float* out, const float* w, const float* bias, const float* alpha,
                      const float* beta, const float* residual, const int32_t* lens, int B, int c_in,
                      int c_out, int k, int T, int act, int layout, float* split_ws, int n_cu, hipStream_t s) {
-  int dev = 0;
-  TACO_HIP(hipGetDevice(&dev));
-  const float* zero = (dev >= 0 && dev < 64) ? g_conv_zero[dev] : nullptr;
-  if (!zero) TACO_FAIL(TACO_EINVAL, "taco_conv_prepare has not run on device %d", dev);
+  // the kernel addresses one utterance's input and the weights through 32-bit buffer offsets
+  if ((uint64_t)c_in * (uint64_t)T * 4u >= 0xffffffffull || (uint64_t)c_out * (uint64_t)c_in * (uint64_t)k * 4u >= 0xffffffffull)
+    TACO_FAIL(TACO_EINVAL, "convolution operand of %d x %d columns / %d x %d x %d weights exceeds 4 GiB", c_in, T, c_out, c_in, k);
   const int tiles_t = (T + CV_TT - 1) / CV_TT, tiles_co = (c_out + CV_CO - 1) / CV_CO;
   const int ci = taco_conv_ci(k);
   const int split = split_ws ? taco_conv_split_factor(tiles_t * tiles_co * B, (c_in + ci - 1) / ci, n_cu) : 1;
@@ -543,10 +547,10 @@ int taco_launch_conv(const float* in, float* out, const float* w, const float* b
   case KS:                                                                                          \
     if (layout & 1)                                                                                 \
       hipLaunchKernelGGL((taco_conv_kernel<KS, true>), grid, dim3(256), taco_conv_lds_bytes(KS), s, in, out, w, bias, alpha, beta, \
-                         residual, lens, c_in, c_out, T, act, layout, zero, split, split_ws);       \
+                         residual, lens, c_in, c_out, T, act, layout, split, split_ws);       \
     else                                                                                            \
     hipLaunchKernelGGL((taco_conv_kernel<KS, false>), grid, dim3(256), taco_conv_lds_bytes(KS), s, in, out, w, bias, alpha, beta,  \
-                       residual, lens, c_in, c_out, T, act, layout, zero, split, split_ws);             \
+                       residual, lens, c_in, c_out, T, act, layout, split, split_ws);             \
     break;
     TACO_CONV_CASE(1)
     TACO_CONV_CASE(3)

@@ -186,7 +186,7 @@ def batch64_bf16_record(model, ckpt, device, fp32_record, frames=600, reps=3):
 
 
 def batch64_record(model, ckpt, device, frames=600, reps=3):
-  """BASELINE configs[2]: 64 synthetic lines (40..160 symbols, generator seed 2024, longest first) in one padded batch,
+  """The batched configuration: 64 synthetic lines (40..160 symbols, generator seed 2024, longest first) in one padded batch,
   every line run to `frames` decoder steps: encode + lockstep decoder (one persistent launch, 16 utterances in flight) + postnet."""
   from tacotron_amd import scenarios
   from tacotron_amd.masks import prenet_keep_masks
@@ -287,8 +287,8 @@ def main():
   ap.add_argument("--warmup", type=int, default=3)
   ap.add_argument("--frames", type=int, default=1000, help="decoder frames per utterance (max_decoder_steps)")
   ap.add_argument("--workload", choices=("auto", "b1", "lines"), default="auto",
-                  help="b1: one North-Wind utterance per step at batch 1 (BASELINE configs[1]); lines: the sharded batch-synthesis "
-                       "line set (configs[4]); auto = b1 on one GPU, lines on several")
+                  help="b1: one North-Wind utterance per step at batch 1 (the headline configuration); lines: the sharded batch-synthesis "
+                       "line set; auto = b1 on one GPU, lines on several")
   ap.add_argument("--lines-per-gpu", type=int, default=256, help="lines workload: lines per rank and step")
   ap.add_argument("--batch-size", type=int, default=64, help="lines workload: utterances per padded batch")
   ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline sample size; 0 disables it")
@@ -370,7 +370,7 @@ def main():
       "real_time_factor": round(args.steps * audio_s / elapsed, 1),
       "rank0_frames_per_s": round(my_frames / float(np.mean(rank_s)), 1),
       "per_gpu_frames_per_s": round(value / world, 1),
-      "note": "one GPU runs workload b1 by default (batch-1 latency, BASELINE configs[1]); the one-GPU figure of THIS workload is "
+      "note": "one GPU runs workload b1 by default (batch-1 latency, the headline configuration); the one-GPU figure of THIS workload is "
               "`lines_one_gpu.value` of that run's line (= `--workload lines`): weak-scaling efficiency = value / (n_gpus x that)",
     }
     # the dominant kernel's roofline: measured on this rank's GPU outside the timed region (every rank does the same

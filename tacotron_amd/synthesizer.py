@@ -84,7 +84,9 @@ class _Prepared:
 
 class Synthesizer:
   def __init__(self, checkpoint: CheckpointDict, custom_hparams: Optional[Dict[str, str]] = None,
-               device: Optional[Union[str, torch.device]] = None):
+               device: Optional[Union[str, torch.device]] = None, precision: str = "fp32"):
+    """The reference's constructor (src/tacotron/synthesizer.py:47-91) plus ``precision``: "fp32" (the reference's
+    arithmetic, the default) or "bf16" for the decoder of batches (see ``Tacotron2.set_precision``)."""
     validate(checkpoint)
     self.device = torch.device(device) if device is not None else get_default_device()
     hparams = apply_custom_hparams(get_hparams(checkpoint), custom_hparams)
@@ -111,6 +113,8 @@ class Synthesizer:
                       n_durations=count(self.duration_mapping))
     model.load_state_dict(checkpoint[KEY_MODEL_STATE])
     self.model = model.to(self.device).eval()
+    if precision != "fp32":
+      self.model.set_precision(precision)
     self._staging: Dict[int, torch.Tensor] = {}
 
   def get_sampling_rate(self) -> int:

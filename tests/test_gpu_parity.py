@@ -732,6 +732,11 @@ def test_error_reporting():
       gm.decode(mem_w, pm_w, dev(np.array(wrong, np.int32)), masks, 8)
   out = gm.decode(mem_w, pm_w, lens_ok, masks, 8, gate_threshold=2.0)    # and the handle still works afterwards
   assert out[3].cpu().tolist() == [8, 8]
+  # an unknown precision code is refused at the C ABI and leaves the setting as it was
+  from tacotron_amd import _lib
+  assert _lib.lib().taco_set_precision(gm._require(), 7) == -22
+  assert b"precision" in _lib.lib().taco_last_error()
+  assert _lib.lib().taco_set_precision(gm._require(), 0) == 0
 
 
 def test_synthesize_command_on_gpu_matches_oracle_backed_run(tmp_path):

@@ -201,8 +201,14 @@ __device__ __forceinline__ void bt_store4(__amdgpu_buffer_rsrc_t rs, unsigned wi
 // and store them as one 16-byte piece at word index `widx` (= vector offset + utterance * K + 4 * workgroup).
 template <int R>
 __device__ __forceinline__ void bt_publish_units(__amdgpu_buffer_rsrc_t rs, unsigned widx, int cap, unsigned tag, float hv, int lane) {
-  const float h1 = __shfl(hv, (lane & 15) + 16, 64), h2 = __shfl(hv, (lane & 15) + 32, 64), h3 = __shfl(hv, (lane & 15) + 48, 64);
-  if (lane < 16) bt_store4<R>(rs, widx, cap, tag, hv, h1, h2, h3);
+  // rows of 16 lanes [r0 r1 r2 r3] = the four units: v_permlane16_swap(x, x) leaves [r1 r1 r3 r3] in its second result,
+  // v_permlane32_swap(x, x) [r2 r3 r2 r3], and the 16-swap of that [r3 r3 r3 r3] - three vector instructions where
+  // three __shfl would be three round trips through the LDS crossbar, on the path every other workgroup waits for
+  const unsigned x = __float_as_uint(hv);
+  const auto s16 = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+  const auto s32 = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+  const auto s48 = __builtin_amdgcn_permlane16_swap(s32[1], s32[1], false, false);
+  if (lane < 16) bt_store4<R>(rs, widx, cap, tag, hv, __uint_as_float(s16[1]), __uint_as_float(s32[1]), __uint_as_float(s48[1]));
 }
 
 // B operands come straight from the hand-off words.  bt_issue starts N 16-byte loads (word index widx + 16 i),
@@ -876,8 +882,15 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
             float e = 0.0f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) e = fmaf(vq[r], taco_tanh(q4[r] + u4[r]), e);
-            e += __shfl_xor(e, 16, 64);
-            e += __shfl_xor(e, 32, 64);
+            // (the four quarters of the wave hold four dimensions each of the same 16 positions: v_permlane16_swap /
+            // v_permlane32_swap put a lane's partner quarter beside it in one vector instruction each, where a
+            // __shfl_xor is a round trip through the LDS crossbar; same additions, same bits)
+            {
+              const auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(e), __float_as_uint(e), false, false);
+              e = __uint_as_float(r16[0]) + __uint_as_float(r16[1]);
+              const auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(e), __float_as_uint(e), false, false);
+              e = __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
+            }
             // four neighbouring positions meet in the first lane of their quad: one 16-byte store of tagged words
             e = s < len ? e : 0.0f;
             const float e1 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(e), 0x55, 0xf, 0xf, true));

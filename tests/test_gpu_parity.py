@@ -764,3 +764,32 @@ def test_synthesize_command_on_gpu_matches_oracle_backed_run(tmp_path):
       want, got = np.load(tmp_path / "oracle" / n), np.load(tmp_path / sub / n)
       assert got.shape == want.shape and got.dtype == np.float32
       np.testing.assert_allclose(got, want, atol=FREE_TOL, rtol=0)
+
+
+@pytest.mark.parametrize("k_enc,k_post", [(3, 7), (9, 3), (7, 9), (1, 1)])
+def test_convolutions_of_other_kernel_sizes_match_oracle(k_enc, k_post):
+  """Every kernel size the convolution kernel is instantiated for (the goldens only have 5): encoder and postnet of a
+  small model with other sizes against the oracle (itself checked against plain torch for these sizes in
+  tests/test_oracle_golden.py), one utterance and a ragged batch, short enough that several workgroups share a tile."""
+  from oracle.oracle import OracleModel
+  from tacotron_amd.model import Tacotron2
+  from test_oracle_golden import other_kernel_checkpoint
+  ck = other_kernel_checkpoint(k_enc, k_post)
+  om = OracleModel(ck)
+  hp = ckpt_mod.get_hparams(ck)
+  gm = Tacotron2(hp, **abi.mapping_counts(ck, hp))
+  gm.load_state_dict(ck["model_state"])
+  gm.to("cuda:0").eval()
+  lens = [70, 23, 41]
+  ids = scenarios.random_ids(ck, lens, seed=k_enc)
+  for b in range(len(lens)):
+    ids["speakers"][b, :] = ids["speakers"][b, 0]
+  ln = np.array(lens, np.int32)
+  mem_o, pm_o = om.encode(chans(ids), ids["speakers"], ln)
+  mem, pm = gm.encode([dev(c) for c in chans(ids)], dev(ids["speakers"]), dev(ln))
+  np.testing.assert_allclose(mem.cpu().numpy(), mem_o, atol=TF_TOL, rtol=0)
+  np.testing.assert_allclose(pm.cpu().numpy(), pm_o, atol=TF_TOL, rtol=0)
+  mel = np.random.RandomState(k_post).randn(3, om.dims.n_mel, 150).astype(np.float32)
+  nf = np.array([150, 64, 9], np.int32)
+  post = gm.postnet(dev(mel), dev(nf))
+  np.testing.assert_allclose(post.cpu().numpy(), om.postnet(mel, nf), atol=2e-4, rtol=0)

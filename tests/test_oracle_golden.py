@@ -132,3 +132,47 @@ def test_oracle_on_the_published_checkpoint_matches_the_reference_component_test
   assert result.mel_outputs_postnet.shape == (80, 214)
   np.testing.assert_allclose(result.mel_outputs_postnet[:5, :5], _KAT_CORNER, atol=1e-4, rtol=0)
   assert result.duration_s == 2.4729251700680273
+
+
+def _torch_postnet(state, mel, n_post):
+  """Postnet.forward + the residual as plain PyTorch fp32 ops (reference: src/tacotron/model.py:205-211, 788-789):
+  Conv1d(padding (k - 1) / 2) -> BatchNorm1d in eval mode -> tanh (all but the last layer), added to the input."""
+  import torch.nn.functional as F
+  x = torch.from_numpy(mel)
+  for l in range(n_post):
+    p = f"postnet.convolutions.{l}"
+    w = state[f"{p}.0.conv.weight"]
+    x = F.conv1d(x, w, state[f"{p}.0.conv.bias"], padding=(w.shape[2] - 1) // 2)
+    x = F.batch_norm(x, state[f"{p}.1.running_mean"], state[f"{p}.1.running_var"], state[f"{p}.1.weight"], state[f"{p}.1.bias"],
+                     training=False, eps=1e-5)
+    if l < n_post - 1:
+      x = torch.tanh(x)
+  return (torch.from_numpy(mel) + x).numpy()
+
+
+OTHER_KERNEL_SIZES = [(3, 7), (9, 3), (7, 9), (1, 1)]      # (encoder_kernel_size, postnet_kernel_size); the goldens all use 5
+
+
+def other_kernel_checkpoint(k_enc, k_post):
+  from tacotron_amd import synth
+  return synth.make_checkpoint(synth.tiny_hparams(encoder_kernel_size=k_enc, postnet_kernel_size=k_post, postnet_embedding_dim=40),
+                               n_symbols=30, seed=3 + k_enc)
+
+
+@pytest.mark.parametrize("k_enc,k_post", OTHER_KERNEL_SIZES)
+def test_oracle_convolutions_of_other_kernel_sizes_match_plain_torch(k_enc, k_post):
+  """The reference's goldens all have kernel size 5; the other sizes the library instantiates (1, 3, 7, 9) are pinned
+  here for the oracle against the same layer stack written with torch's own conv1d / batch_norm."""
+  from oracle.oracle import OracleModel
+  ck = other_kernel_checkpoint(k_enc, k_post)
+  om = OracleModel(ck)
+  assert (om.dims.k_enc, om.dims.k_post) == (k_enc, k_post)
+  mel = np.random.RandomState(k_post).randn(2, om.dims.n_mel, 45).astype(np.float32)
+  want = _torch_postnet(ck["model_state"], mel, om.dims.n_post)
+  got = om.postnet(mel, None)
+  np.testing.assert_allclose(got, want, atol=5e-5, rtol=0)
+  # ragged: the second utterance has 17 frames - its convolutions pad at ITS end, and everything past it is zero
+  got2 = om.postnet(mel, np.array([45, 17], np.int32))
+  mel17 = np.ascontiguousarray(mel[1:2, :, :17])
+  np.testing.assert_allclose(got2[1, :, :17], _torch_postnet(ck["model_state"], mel17, om.dims.n_post)[0], atol=5e-5, rtol=0)
+  assert not got2[1, :, 17:].any()

@@ -152,3 +152,32 @@ def test_reference_component_test_on_the_published_checkpoint():
   assert result.mel_outputs is None and result.gate_outputs is None and result.alignments is None
   assert result.duration_s == 2.4729251700680273
   assert result.inference_duration_s > 0
+
+
+def test_synthesize_command_with_the_bf16_setting(tmp_path, gate_table):
+  """--precision bf16 reaches the lockstep decoder through the command: 24 ragged lines in batches of 12 on the
+  full-size checkpoint, every file written, the first 40 frames of every line within 2e-3 of the files the same command
+  writes in its default precision, and at least one frame differing (the flag is not a no-op)."""
+  from tacotron_amd import cli
+  from tacotron_amd.checkpoint import save_checkpoint
+  ckpt = scenario_checkpoint("ljs", gate_table["ljs"])
+  path = tmp_path / "ljs_synthetic.pt"
+  save_checkpoint(ckpt, path)
+  lines, _ = _ragged_lines(ckpt, 24, 20, 200, seed=77)
+  text = tmp_path / "lines.txt"
+  text.write_text("\n".join(lines), encoding="UTF-8")
+  common = ["synthesize", str(path), str(text), "--sep", "|", "--custom-seed", "3", "--max-decoder-steps", "120",
+            "--device", "cuda:0", "--batch-size", "12"]
+  for sub, extra in (("fp32", []), ("bf16", ["--precision", "bf16"])):
+    ns = cli.build_parser().parse_args(common + ["-out", str(tmp_path / sub)] + extra)
+    assert ns.handler(ns)
+  names = [f"{i:02d}-{i:02d}.npy" for i in range(1, 25)]
+  assert sorted(p.name for p in (tmp_path / "bf16").iterdir()) == names
+  worst, differs = 0.0, False
+  for name in names:
+    a, b = np.load(tmp_path / "fp32" / name), np.load(tmp_path / "bf16" / name)
+    assert a.dtype == b.dtype == np.float32 and np.isfinite(b).all()
+    n = min(a.shape[1], b.shape[1], 40)
+    worst = max(worst, float(np.abs(a[:, :n] - b[:, :n]).max()))
+    differs = differs or a.shape != b.shape or not np.array_equal(a, b)
+  assert worst <= 2e-3 and differs, worst

@@ -54,6 +54,7 @@
 #include "taco_device.h"
 
 #include <math.h>
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -670,6 +671,12 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
 #ifdef TACO_BT_STAMPS
   const int stamp_wg = j == 0 ? 0 : j == n_p_wg ? 1 : j == q_off ? 2 : j == a.n_wg - 1 ? 3 : -1;
 #endif
+  // The frame loop exists once per role (plain LSTM rows only, P, M, Q): a workgroup's role never changes, and a loop
+  // that knows its role at compile time keeps only that role's values in registers - the one loop for all roles needed
+  // the union of them and spilled.
+  auto frame_loop = [&](auto role_tag) __attribute__((always_inline)) {
+  constexpr int ROLE = decltype(role_tag)::value;
+  constexpr bool is_p = ROLE == 1, is_m = ROLE == 2, is_q = ROLE == 3;
   for (;; ++t) {
     const unsigned ep = (unsigned)t + 1u;                                  // epoch of the 8-byte granules
     const unsigned tag = (((unsigned)t >> 1) & 1u) + 1u;                   // generation of this frame's words
@@ -1288,6 +1295,11 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
     if (is_q) update_location_term(lane_f);
     BT_STAMP(14);
   }
+  };
+  if (is_p) frame_loop(std::integral_constant<int, 1>{});
+  else if (is_m) frame_loop(std::integral_constant<int, 2>{});
+  else if (is_q) frame_loop(std::integral_constant<int, 3>{});
+  else frame_loop(std::integral_constant<int, 0>{});
 
   if (j == 0 && tid == 0) {
     a.ctl->n_frames = (uint32_t)t;       // lockstep frames of the launch

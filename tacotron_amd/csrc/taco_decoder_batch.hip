@@ -90,7 +90,7 @@ constexpr int QR = 16 / NW;            // query rows per wave (4)
 constexpr int LOC_KSTEPS = 16;
 constexpr int RP = TACO_BT_ROWS;       // rows per P / M workgroup (one MFMA tile)
 constexpr int W1_KSTEPS = (TACO_MAX_MEL + 3) / 4;    // 20
-static_assert(2 * TACO_MAX_K <= 4 * LOC_KSTEPS, "location taps fit 16 steps of 4");
+static_assert(TACO_MAX_K <= 32 && LOC_KSTEPS == 16, "location taps: 8 steps of 4 for each of the two weight arrays");
 static_assert(QR == 4 && QT % 2 == 0 && CPG * CQ <= NT && MEMW % 4 == 0 && NQ * MEMW >= 544, "Q thread maps");
 static_assert(NL_H % BURST == 0 && NL_P == BURST, "burst structure");
 
@@ -154,7 +154,7 @@ struct BatArgs {
   unsigned long long* frame_clock;
   int frame_clock_cap;
 #ifdef TACO_BT_STAMPS
-  unsigned long long* stamps;     // diagnostic build only: [4 workgroups][BT_STAMP_FRAMES][BT_STAMP_POINTS]
+  unsigned long long* stamps;     // diagnostic build only: [workgroups][BT_STAMP_FRAMES][BT_STAMP_POINTS]
 #endif
 };
 
@@ -532,8 +532,9 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
     }
     _Pragma("unroll 1") for (int i = tid; i < LOC_KSTEPS * 64; i += NT) {
       const int m = i >> 6, l = i & 63;
-      const int ck = 4 * m + (l >> 4), dim = q_base + (l & 15);
-      lds[LQ_E + i] = (ck < 2 * K && (l & 15) < q_cnt) ? a.loc_fold[(size_t)dim * 2 * K + ck] : 0.0f;
+      const int ck = 4 * m + (l >> 4), dim = q_base + (l & 15);       // tap 32 c + k, see update_location_term
+      const int c = ck >> 5, k = ck & 31;
+      lds[LQ_E + i] = (k < K && (l & 15) < q_cnt) ? a.loc_fold[((size_t)dim * 2 + c) * K + k] : 0.0f;
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -545,7 +546,7 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
   wctx.abort_word = (taco_gu32*)&a.ctl->abort_code;
   wctx.failed = 0;
   wctx.spun = 0;
-  int nap_h1 = 0, nap_p = 0, nap_ahq = 0, nap_ah = 0, nap_pe = 0, nap_ctx = 0, nap_dh = 0;
+  int nap_h1 = 0, nap_p = 0, nap_ahq = 0, nap_ah = 0, nap_ctx = 0, nap_dh = 0;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.words, 0, (int)a.words_bytes, 0x00020000);
 
   // Q: the location term of my tiles, U = processed memory + sum over taps of E * {previous, cumulative} weights.
@@ -592,9 +593,12 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
   if (is_q) fill_slot();
   __syncthreads();
   // (lane_o: the lane number behind a compiler barrier, taken anew every frame, see BT_OPQ.)
+  // Taps are numbered 32 c + k (c = 0: previous weights, 1: cumulative weights; k >= K carries a zero filter value), so
+  // that step m = 8 c + k / 4 reads weight number k of array c at a compile-time distance from one per-lane address:
+  // the loop has no address arithmetic, only LDS reads at immediate offsets beside the products.
   auto update_location_term = [&](int lane_o) {
     const int col = lane_o & 15, kqo = lane_o >> 4;
-    const int x_base = BT_OPQ(LQ_AW + HALO + col + kqo - pad);     // LDS index of tap kq at position 0 (previous weights)
+    const float* x_lane = lds + BT_OPQ(LQ_AW + HALO + col + kqo - pad);     // tap kq of the previous weights at position `col`
     const float* e_lane = lds + BT_OPQ(LQ_E + lane_o);
     float* u_lane = lds + BT_OPQ(LQ_U + col * QD + 4 * kqo);
 #pragma unroll
@@ -605,19 +609,18 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
         float pm0[4], pm1[4];
         load_pm(s0 + col, pm0);
         load_pm(s1c + col, pm1);
+        const float* xa = x_lane + s0;
+        const float* xb = x_lane + s1c;
         f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
-        // tap ck = 4 m + kq: previous weights for ck < K, cumulative weights (tap ck - K) from K on; taps beyond 2K
-        // meet a zero in A, any valid address will do.  Operands are read four steps ahead of their products.
-        float ev[2][4], x0[2][4], x1[2][4];
-        auto read_group = [&](int gq, float (&e)[4], float (&xa)[4], float (&xb)[4]) {
+        float ev[2][4], x0[2][4], x1[2][4];      // operands are read four steps ahead of their products
+        auto read_group = [&](int gq, float (&e)[4], float (&x_a)[4], float (&x_b)[4]) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int m = 4 * gq + i;
-            const int ck = 4 * m + kqo;
-            const int off = x_base + 4 * m + (ck >= K ? (ck < 2 * K ? LQ_CUM - LQ_AW - K : -4 * m - kqo) : 0);
+            const int off = (m >> 3) * (LQ_CUM - LQ_AW) + ((4 * m) & 31);
             e[i] = e_lane[m * 64];
-            xa[i] = lds[off + s0];
-            xb[i] = lds[off + s1c];
+            x_a[i] = xa[off];
+            x_b[i] = xb[off];
           }
         };
         read_group(0, ev[0], x0[0], x1[0]);
@@ -669,7 +672,7 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
   }
 
 #ifdef TACO_BT_STAMPS
-  const int stamp_wg = j == 0 ? 0 : j == n_p_wg ? 1 : j == q_off ? 2 : j == a.n_wg - 1 ? 3 : -1;
+  const int stamp_wg = j;
 #endif
   // The frame loop exists once per role (plain LSTM rows only, P, M, Q): a workgroup's role never changes, and a loop
   // that knows its role at compile time keeps only that role's values in registers - the one loop for all roles needed
@@ -715,6 +718,7 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
         }
         bt_check<NL_P, 0, NL_P>(rs, par + w_lane_h1, tag, v, wctx, 0x300u);
         nap_h1 = bt_nap_adjust(nap_h1, wctx.spun);
+        BT_STAMP(23);
         BT_SB();
         f32x4 acc2 = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -915,6 +919,7 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
     //              (next frame) on the same operands ============
     f32x4 acc_d = acc_dn;
     f32x4 acc_an = {0.0f, 0.0f, 0.0f, 0.0f};
+    u32x4 v_pe[2];          // Q: my share of the slot's partial energies
     {
       u32x4 vah[NL_H];
       f32x4 acc_d2 = {0.0f, 0.0f, 0.0f, 0.0f}, acc_an2 = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -939,7 +944,15 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
     BT_MFMA4(wa_h, i, vah[i], acc_an, acc_an2)                                                     \
   }                                                                                                \
   BT_SB();
-      BT_AH_BURST(0) BT_AH_BURST(1)
+      BT_AH_BURST(0)
+      if constexpr (is_q) {
+        // the partial energies of my utterance are asked for here, a burst of products ahead of their use: their round
+        // trip runs beside the second burst instead of after it
+#pragma unroll
+        for (int i = 0; i < 2; ++i) v_pe[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (par + pe_src0 + 128u * i) * 4u, 0, 16);
+        BT_SB();
+      }
+      BT_AH_BURST(1)
       if (!is_q) { BT_AH_BURST(2) BT_AH_BURST(3) }
 #undef BT_AH_BURST
       acc_d += acc_d2;
@@ -952,14 +965,18 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
       {
         // partial energies of my utterance's 8 workgroups: thread (group tid >> 5, l = tid & 31) takes positions
         // 4 l .. 4 l + 3 and 4 (l + 32) .. of that group
-        u32x4 v[2];
+        u32x4 (&v)[2] = v_pe;
         const unsigned src = par + pe_src0;
         const int pd = BT_OPQ(LQ_XPE + (tid_f >> 5) * TIN + 4 * (tid_f & 31));
         unsigned spins = 0;
-        bt_nap_begin(nap_pe, wctx);
+        bool again = false;
+        wctx.spun = 0;
         for (;;) {
+          if (again) {
 #pragma unroll
-          for (int i = 0; i < 2; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (src + 128u * i) * 4u, 0, 16);
+            for (int i = 0; i < 2; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (src + 128u * i) * 4u, 0, 16);
+          }
+          again = true;
           unsigned bad = 0;
 #pragma unroll
           for (int i = 0; i < 2; ++i)
@@ -978,7 +995,6 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
           }
           asm volatile("" ::: "memory");
         }
-        nap_pe = bt_nap_adjust(nap_pe, wctx.spun);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
           if (i < pe_n) *reinterpret_cast<float4*>(lds + pd + 128 * i) = make_float4(BT_F(v[i].x), BT_F(v[i].y), BT_F(v[i].z), BT_F(v[i].w));
@@ -1130,7 +1146,9 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
 #pragma unroll
       for (int i = 6; i < 9; ++i) { BT_MFMA4(wd_c, i, vc[i], acc_d, acc_d2) }
       acc_d += acc_d2;
+      BT_STAMP(20);
       const f32x4 pre = bt_reduce_tiles(lds, L_RED, acc_d, wave, lane_f);
+      BT_STAMP(21);
       if (wave == 0) {
         const f32x4 bias = *reinterpret_cast<const f32x4*>(lds + L_BIAS + 16 + 4 * kq_f);
         const float hv = bt_lstm_cell(pre, bias, c_d);
@@ -1292,6 +1310,7 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
       }
     }
     // Q: next frame's location term, while the P group works on the next frame's prenet output
+    BT_STAMP(22);
     if (is_q) update_location_term(lane_f);
     BT_STAMP(14);
   }
@@ -1398,38 +1417,62 @@ int taco_decoder_batch_prepare(taco_handle h) {
 #ifdef TACO_BT_STAMPS
 #include <stdio.h>
 static unsigned long long* g_bt_stamps = nullptr;
-// Diagnostic build: when each stamp point of the last launch is reached, per stamped workgroup, on the common clock
-// (mean over the frames, measured from the first P workgroup's frame top), in the order in which they are reached.
+// Diagnostic build: when each stamp point of the last launch is reached, on the common clock, in microseconds from the
+// first P workgroup's frame top of the same frame (mean over the frames): a timeline of four single workgroups, then
+// per stamp point the earliest / mean / latest workgroup of each role.
 void taco_decoder_batch_dump_stamps(int n_frames) {
   if (!g_bt_stamps) return;
-  const size_t n = (size_t)4 * BT_STAMP_FRAMES * BT_STAMP_POINTS;
+  constexpr int NWG = TACO_BT_WGS;
+  const size_t n = (size_t)NWG * BT_STAMP_FRAMES * BT_STAMP_POINTS;
   std::vector<unsigned long long> st(n);
   if (hipMemcpy(st.data(), g_bt_stamps, n * 8, hipMemcpyDeviceToHost) != hipSuccess) return;
   const int nfr = n_frames < BT_STAMP_FRAMES ? n_frames : BT_STAMP_FRAMES;
-  static const char* wgn[4] = {"P (0)", "M (first)", "Q (first)", "plain (last)"};
   static const char* names[BT_STAMP_POINTS] = {"frame top: P layer 2 done, p published", "stop test done", "p loaded", "att MFMA+reduce+cell, ah published",
       "Q: ah of my utterance gathered", "Q: query+energies, pe published", "ah loads + products done", "Q: pe gathered", "Q: softmax+ctx, ctx published",
       "P/M: all row products issued", "ctx first burst loaded", "dec MFMA+reduce+cell, dh published", "slack products done, dh first burst loaded",
       "P/M: rows reduced, epilogue, h1 / frame published", "recurrent MFMAs (+ Q: location term) done", "P/M: tiles reduced",
-      "Q: query values in LDS", "Q: energies summed, exp done", "Q: weights normalised, in LDS", "Q: context partial sums in LDS", "", "", "", ""};
-  for (int wg = 0; wg < 4; ++wg) {
-    double at[BT_STAMP_POINTS] = {0};
-    int cnt[BT_STAMP_POINTS] = {0};
+      "Q: query values in LDS", "Q: energies summed, exp done", "Q: weights normalised, in LDS", "Q: context partial sums in LDS",
+      "ctx: all bursts loaded, products issued", "dec tiles reduced", "recurrent products done (before Q's location term)", "P: h1 loaded (frame top)"};
+  const int n_p = KP / RP, n_m = (TACO_MAX_MEL + 1 + RP - 1) / RP, q_off = n_p + n_m;
+  std::vector<double> at((size_t)NWG * BT_STAMP_POINTS, 0.0);
+  std::vector<int> cnt((size_t)NWG * BT_STAMP_POINTS, 0);
+  for (int wg = 0; wg < NWG; ++wg)
     for (int t = 40; t + 1 < nfr; ++t) {
       const unsigned long long* r = &st[((size_t)wg * BT_STAMP_FRAMES + t) * BT_STAMP_POINTS];
       const unsigned long long base = st[((size_t)0 * BT_STAMP_FRAMES + t) * BT_STAMP_POINTS];
       for (int k = 0; k < BT_STAMP_POINTS; ++k)
-        if (r[k] != 0) { at[k] += ((double)r[k] - (double)base) * 0.01; ++cnt[k]; }
+        if (r[k] != 0) { at[(size_t)wg * BT_STAMP_POINTS + k] += ((double)r[k] - (double)base) * 0.01; ++cnt[(size_t)wg * BT_STAMP_POINTS + k]; }
     }
+  for (size_t i = 0; i < at.size(); ++i) if (cnt[i] > 0) at[i] /= cnt[i];
+  const int shown[4] = {0, n_p, q_off, NWG - 1};
+  static const char* wgn[4] = {"P (0)", "M (first)", "Q (first)", "plain (last)"};
+  for (int w = 0; w < 4; ++w) {
+    const int wg = shown[w];
     int order[BT_STAMP_POINTS], m = 0;
-    for (int k = 0; k < BT_STAMP_POINTS; ++k)
-      if (cnt[k] > 0) { at[k] /= cnt[k]; order[m++] = k; }
+    for (int k = 0; k < BT_STAMP_POINTS; ++k) if (cnt[(size_t)wg * BT_STAMP_POINTS + k] > 0) order[m++] = k;
     if (m == 0) continue;
+    const double* a0 = &at[(size_t)wg * BT_STAMP_POINTS];
     for (int x = 1; x < m; ++x)
-      for (int y = x; y > 0 && at[order[y]] < at[order[y - 1]]; --y) { const int z = order[y]; order[y] = order[y - 1]; order[y - 1] = z; }
-    fprintf(stderr, "[bt stamps] workgroup %s (us from the P group's frame top; step since the point before):\n", wgn[wg]);
+      for (int y = x; y > 0 && a0[order[y]] < a0[order[y - 1]]; --y) { const int z = order[y]; order[y] = order[y - 1]; order[y - 1] = z; }
+    fprintf(stderr, "[bt stamps] workgroup %s (us from the P group's frame top; step since the point before):\n", wgn[w]);
     for (int x = 0; x < m; ++x)
-      fprintf(stderr, "  %7.2f  %+6.2f  %s\n", at[order[x]], x ? at[order[x]] - at[order[x - 1]] : 0.0, names[order[x]]);
+      fprintf(stderr, "  %7.2f  %+6.2f  %s\n", a0[order[x]], x ? a0[order[x]] - a0[order[x - 1]] : 0.0, names[order[x]]);
+  }
+  static const char* rolen[4] = {"P", "M", "Q", "plain"};
+  fprintf(stderr, "[bt stamps] per stamp point and role: earliest / mean / latest workgroup (its number)\n");
+  for (int k = 0; k < BT_STAMP_POINTS; ++k) {
+    for (int role = 0; role < 4; ++role) {
+      double lo = 1e30, hi = -1e30, sum = 0.0; int c = 0, wlo = -1, whi = -1;
+      for (int wg = 0; wg < NWG; ++wg) {
+        const int r = wg < n_p ? 0 : wg < q_off ? 1 : wg < q_off + NB * NQ ? 2 : 3;
+        if (r != role || cnt[(size_t)wg * BT_STAMP_POINTS + k] == 0) continue;
+        const double v = at[(size_t)wg * BT_STAMP_POINTS + k];
+        if (v < lo) { lo = v; wlo = wg; }
+        if (v > hi) { hi = v; whi = wg; }
+        sum += v; ++c;
+      }
+      if (c > 0) fprintf(stderr, "  [%2d] %-5s %7.2f (%3d) / %7.2f / %7.2f (%3d)  %s\n", k, rolen[role], lo, wlo, sum / c, hi, whi, names[k]);
+    }
   }
 }
 #endif
@@ -1469,7 +1512,7 @@ int taco_launch_decoder_batch(taco_handle h, const float* memory, const float* p
   TACO_HIP(hipMemsetAsync(h->bat_gran, 0, a.words_bytes, s));
 #ifdef TACO_BT_STAMPS
   {
-    const size_t n = (size_t)4 * BT_STAMP_FRAMES * BT_STAMP_POINTS;
+    const size_t n = (size_t)TACO_BT_WGS * BT_STAMP_FRAMES * BT_STAMP_POINTS;
     if (!g_bt_stamps) TACO_HIP(hipMalloc((void**)&g_bt_stamps, n * 8));
     TACO_HIP(hipMemsetAsync(g_bt_stamps, 0, n * 8, s));
     a.stamps = g_bt_stamps;

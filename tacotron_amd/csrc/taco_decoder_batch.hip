@@ -159,14 +159,20 @@ struct BatArgs {
 };
 
 #ifdef TACO_BT_STAMPS
-constexpr int BT_STAMP_FRAMES = 256, BT_STAMP_POINTS = 24;
+constexpr int BT_STAMP_FRAMES = 256, BT_STAMP_POINTS = 32;
 #define BT_STAMP(k)                                                                                         \
   do {                                                                                                      \
     if (tid == 0 && stamp_wg >= 0 && t < BT_STAMP_FRAMES)                                                   \
       a.stamps[((size_t)stamp_wg * BT_STAMP_FRAMES + t) * BT_STAMP_POINTS + (k)] = wall_clock64();          \
   } while (0)
+#define BT_STAMP_W(k, w)                                                                                   \
+  do {                                                                                                      \
+    if (tid == 64 * (w) && stamp_wg >= 0 && t < BT_STAMP_FRAMES)                                            \
+      a.stamps[((size_t)stamp_wg * BT_STAMP_FRAMES + t) * BT_STAMP_POINTS + (k)] = wall_clock64();          \
+  } while (0)
 #else
 #define BT_STAMP(k) do {} while (0)
+#define BT_STAMP_W(k, w) do {} while (0)
 #endif
 
 // An LDS index behind a compiler barrier.  The carve of a Q workgroup reaches far past the 64 KB an LDS instruction's
@@ -279,6 +285,24 @@ __device__ __forceinline__ float bt_lstm_cell(f32x4 pre, f32x4 bias, float& c) {
 // second fetch of a burst, less than a nap that is too long costs every frame (measured on the batch of 64: 4 : 1 -0.4 %,
 // 8 : 1 +1.2 %, 16 : 1 = the batch-1 kernel's ratio 0, 32 : 1 -3.3 %, 64 : 1 -7.7 %; no naps at all -15 %).
 constexpr int BT_NAP_UP = 8, BT_NAP_DOWN = 1;
+// Extra time (units of s_sleep 1, about 64 clocks) that workgroups not on the frame's chain keep away from a vector
+#ifndef BT_DELAY_AH
+#define BT_DELAY_AH 50
+#endif
+// Whether a vector's nap is steered by all its bursts (1: a look is early if ANY piece of the vector was not there) or by
+// the first one only
+#ifndef BT_NAPALL_AH
+#define BT_NAPALL_AH 1
+#endif
+#ifndef BT_NAPALL_CTX
+#define BT_NAPALL_CTX 1
+#endif
+#ifndef BT_NAPALL_DH
+#define BT_NAPALL_DH 1
+#endif
+#ifndef BT_DELAY_DH
+#define BT_DELAY_DH 0
+#endif
 __device__ __forceinline__ int bt_nap_adjust(int n, int spun) {
   const bool any = __builtin_amdgcn_readfirstlane(__any(spun) ? 1 : 0) != 0;
   return any ? min(n + BT_NAP_UP, TACO_NAP_MAX) : max(n - BT_NAP_DOWN, 0);
@@ -843,6 +867,7 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
     }
     BT_STAMP(3);
 
+    u32x4 vah[NL_H];        // the attention hidden state of all utterances: my wave's share of its columns
     // ============ Q: query values and partial energies of my 16 dimensions, every position of my utterance ============
     if (is_q) {
       {
@@ -855,6 +880,14 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
         bt_check<1, 0, 1>(rs, src, tag, v, wctx, 0x500u);
         nap_ahq = bt_nap_adjust(nap_ahq, wctx.spun);
         *reinterpret_cast<float4*>(lds + BT_OPQ(LQ_XPE + 4 * tid_f)) = make_float4(BT_F(v[0].x), BT_F(v[0].y), BT_F(v[0].z), BT_F(v[0].w));
+#ifndef BT_NO_AH_AHEAD
+        // the first half of everybody's hidden state (its products run while the partial energies travel) is asked for
+        // now, a query and an energy stage ahead: my utterance's values have come from all the workgroups, so the
+        // other utterances' are there too as a rule, and their round trip is over when the products begin
+        BT_SB();
+#pragma unroll
+        for (int i = 0; i < NL_H / 2; ++i) vah[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (par + w_lane_ah + 256u * i) * 4u, 0, 16);
+#endif
       }
       taco_lds_barrier();
       BT_STAMP(4);
@@ -921,23 +954,26 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
     f32x4 acc_an = {0.0f, 0.0f, 0.0f, 0.0f};
     u32x4 v_pe[2];          // Q: my share of the slot's partial energies
     {
-      u32x4 vah[NL_H];
       f32x4 acc_d2 = {0.0f, 0.0f, 0.0f, 0.0f}, acc_an2 = {0.0f, 0.0f, 0.0f, 0.0f};
-      bt_nap_begin(nap_ah, wctx);
       if (is_q) {
         // a Q workgroup has the softmax ahead of it and everybody waiting for its context: it takes half of the vector
         // here - about what the partial energies take to travel - and the other half while its context travels
+        wctx.spun = 0;
+#ifdef BT_NO_AH_AHEAD
 #pragma unroll
         for (int i = 0; i < NL_H / 2; ++i) vah[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (par + w_lane_ah + 256u * i) * 4u, 0, 16);
-#pragma unroll
-        for (int i = NL_H / 2; i < NL_H; ++i) vah[i] = u32x4{tag, tag, tag, tag};
+#endif
       } else {
+        // nobody but the Q workgroups is in a hurry for this vector (its products are needed when the context arrives):
+        // the others stay away from memory a little longer, so that the Q workgroups' fetches are served first
+        for (int i = 0; i < BT_DELAY_AH; ++i) __builtin_amdgcn_s_sleep(1);
+        bt_nap_begin(nap_ah, wctx);
         bt_issue<NL_H>(rs, par + w_lane_ah, vah);
       }
       BT_SB();
 #define BT_AH_BURST(c)                                                                             \
   bt_check<NL_H, BURST * (c), BURST>(rs, par + w_lane_ah, tag, vah, wctx, 0x600u);                  \
-  if ((c) == 0) nap_ah = bt_nap_adjust(nap_ah, wctx.spun);                                       \
+  if ((c) == (BT_NAPALL_AH ? (is_q ? 1 : 3) : 0)) nap_ah = bt_nap_adjust(nap_ah, wctx.spun);       \
   BT_SB();                                                                                         \
   _Pragma("unroll") for (int i = BURST * (c); i < BURST * (c) + BURST; ++i) {                      \
     BT_MFMA4(wd_a, i, vah[i], acc_d, acc_d2)                                                       \
@@ -1130,7 +1166,7 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
       }
       BT_SB();
       bt_check<NL_C, 0, 3>(rs, par + w_lane_c, tag, vc, wctx, 0x800u);
-      nap_ctx = bt_nap_adjust(nap_ctx, wctx.spun);
+      if (!BT_NAPALL_CTX) nap_ctx = bt_nap_adjust(nap_ctx, wctx.spun);
       BT_STAMP(10);
       BT_SB();
 #pragma unroll
@@ -1142,11 +1178,13 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
       for (int i = 3; i < 6; ++i) { BT_MFMA4(wd_c, i, vc[i], acc_d, acc_d2) }
       BT_SB();
       bt_check<NL_C, 6, 3>(rs, par + w_lane_c, tag, vc, wctx, 0x800u);
+      if (BT_NAPALL_CTX) nap_ctx = bt_nap_adjust(nap_ctx, wctx.spun);
       BT_SB();
 #pragma unroll
       for (int i = 6; i < 9; ++i) { BT_MFMA4(wd_c, i, vc[i], acc_d, acc_d2) }
       acc_d += acc_d2;
       BT_STAMP(20);
+      BT_STAMP_W(24, 1); BT_STAMP_W(25, 2); BT_STAMP_W(26, 3);
       const f32x4 pre = bt_reduce_tiles(lds, L_RED, acc_d, wave, lane_f);
       BT_STAMP(21);
       if (wave == 0) {
@@ -1199,6 +1237,9 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
     // ============ the decoder hidden state; P: next frame's layer-1 rows; M: the frame's output ============
     {
       u32x4 vdh[NL_H];
+      // (the P workgroups head the next frame with this vector and the M workgroups make the frame of it; the others need
+      // it for products that have until the next context to finish, and let those two groups fetch first)
+      if (!(is_p || is_m)) { for (int i = 0; i < BT_DELAY_DH; ++i) __builtin_amdgcn_s_sleep(1); }
       bt_nap_begin(nap_dh, wctx);
       bt_issue<NL_H>(rs, par + w_lane_dh, vdh);
       BT_SB();
@@ -1221,7 +1262,8 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
       }                                                                                            \
     }                                                                                              \
     bt_check<NL_H, BURST * (c), BURST>(rs, par + w_lane_dh, tag, vdh, wctx, 0x900u);                \
-    if ((c) == 0) { nap_dh = bt_nap_adjust(nap_dh, wctx.spun); BT_STAMP(12); }                   \
+    if ((c) == 0) { BT_STAMP(12); }                                                              \
+    if ((c) == (BT_NAPALL_DH ? 3 : 0)) nap_dh = bt_nap_adjust(nap_dh, wctx.spun);                  \
     BT_SB();                                                                                       \
     if (use_rows) {                                                                                \
       if (rows_bf) {                                                                               \
@@ -1239,6 +1281,7 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
 #undef BT_ROWS_BURST
         acc_r += acc_r2;
         BT_STAMP(9);
+        BT_STAMP_W(27, 1); BT_STAMP_W(28, 3);
         if (is_p && forced) {
           // teacher forcing: the plain layer-1 rows on the given frame (wave w takes k-steps 5w .. 5w + 4)
           constexpr int W1_PER_WAVE = (W1_KSTEPS + NW - 1) / NW;
@@ -1300,7 +1343,8 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
         f32x4 acc_dn2 = {0.0f, 0.0f, 0.0f, 0.0f};
 #define BT_DH_BURST(c)                                                                             \
   bt_check<NL_H, BURST * (c), BURST>(rs, par + w_lane_dh, tag, vdh, wctx, 0x980u);                  \
-  if ((c) == 0) { nap_dh = bt_nap_adjust(nap_dh, wctx.spun); BT_STAMP(12); }                     \
+  if ((c) == 0) { BT_STAMP(12); }                                                                \
+  if ((c) == (BT_NAPALL_DH ? 3 : 0)) nap_dh = bt_nap_adjust(nap_dh, wctx.spun);                    \
   BT_SB();                                                                                         \
   _Pragma("unroll") for (int i = BURST * (c); i < BURST * (c) + BURST; ++i) { BT_MFMA4(wd_h, i, vdh[i], acc_dn, acc_dn2) } \
   BT_SB();
@@ -1432,7 +1476,9 @@ void taco_decoder_batch_dump_stamps(int n_frames) {
       "P/M: all row products issued", "ctx first burst loaded", "dec MFMA+reduce+cell, dh published", "slack products done, dh first burst loaded",
       "P/M: rows reduced, epilogue, h1 / frame published", "recurrent MFMAs (+ Q: location term) done", "P/M: tiles reduced",
       "Q: query values in LDS", "Q: energies summed, exp done", "Q: weights normalised, in LDS", "Q: context partial sums in LDS",
-      "ctx: all bursts loaded, products issued", "dec tiles reduced", "recurrent products done (before Q's location term)", "P: h1 loaded (frame top)"};
+      "ctx: all bursts loaded, products issued", "dec tiles reduced", "recurrent products done (before Q's location term)", "P: h1 loaded (frame top)",
+      "ctx products issued, wave 1", "ctx products issued, wave 2", "ctx products issued, wave 3", "P/M: row products issued, wave 1", "P/M: row products issued, wave 3",
+      "", "", ""};
   const int n_p = KP / RP, n_m = (TACO_MAX_MEL + 1 + RP - 1) / RP, q_off = n_p + n_m;
   std::vector<double> at((size_t)NWG * BT_STAMP_POINTS, 0.0);
   std::vector<int> cnt((size_t)NWG * BT_STAMP_POINTS, 0);

@@ -72,13 +72,22 @@ def lib() -> C.CDLL:
 
 
 ERANGE = -34
+ETIMEDOUT = -110
 
 
 class TacoIndexError(TacoError, IndexError):
   """An input id outside its table (what the reference's embedding lookup raises an IndexError for)."""
 
 
+class TacoTimeoutError(TacoError, TimeoutError):
+  """A persistent kernel gave up waiting for a hand-off (TACO_ETIMEDOUT): its workgroups were not all running at
+  once, which happens when something else holds compute units of the GPU during the call."""
+
+
+_ERROR_TYPES = {ERANGE: TacoIndexError, ETIMEDOUT: TacoTimeoutError}
+
+
 def check(rc: int) -> None:
   if rc != 0:
     message = lib().taco_last_error().decode("utf-8", "replace")
-    raise (TacoIndexError if rc == ERANGE else TacoError)(rc, message)
+    raise _ERROR_TYPES.get(rc, TacoError)(rc, message)

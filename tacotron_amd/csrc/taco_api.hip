@@ -538,6 +538,9 @@ extern "C" int taco_postnet_noalloc(taco_handle h, const float* mel, const int32
   float* scratch = (h->device >= 0 && h->device < 64) ? g_noalloc_ptr[h->device] : nullptr;
   if (!scratch) TACO_FAIL(TACO_EINVAL, "taco_postnet_noalloc: no scratch address for device %d", h->device);
   float* buf[2] = {scratch, scratch + TACO_NOALLOC_HALF};
+  // partial tiles and their counters in the built-in array too: the call stays off every workspace of the handle, so it
+  // may overlap taco_encode / taco_postnet of the same handle on another stream
+  float* split_ws = scratch + 2u * TACO_NOALLOC_HALF;
   const float* cur_in = mel;
   int cur = 0;
   for (int l = 0; l < d.n_post; ++l) {
@@ -547,8 +550,8 @@ extern "C" int taco_postnet_noalloc(taco_handle h, const float* mel, const int32
     // every layer writes all B x c_out x T_cap elements of its output (zeros at or past n_frames[b]), so nothing of the
     // scratch's previous contents is ever read
     const int rc = taco_launch_conv(cur_in, dst, h->w.post_conv_w[l], h->w.post_conv_b[l], h->post_alpha[l], h->post_beta[l],
-                                    last ? mel : nullptr, n_frames, B, c_in, c_out, d.k_post, T_cap, last ? 0 : /*tanh*/ 2, 0, h->conv_split,
-                          h->n_cu, s);
+                                    last ? mel : nullptr, n_frames, B, c_in, c_out, d.k_post, T_cap, last ? 0 : /*tanh*/ 2, 0, split_ws,
+                                    h->n_cu, s);
     if (rc != TACO_OK) return rc;
     cur_in = dst;
     cur ^= 1;

@@ -47,3 +47,34 @@ def test_postnet_noalloc_equals_postnet_on_two_calls_in_a_row():
   with pytest.raises(_lib.TacoError) as err:
     _postnet(gm, L.taco_postnet_noalloc, too_big, nf)
   assert "scratch" in str(err.value)
+
+
+def test_postnet_noalloc_may_overlap_the_encoder_of_the_same_handle():
+  """taco_postnet_noalloc keeps off every workspace of the handle (activations, partial convolution tiles and their
+  counters are all inside the built-in scratch), so it may run on one stream while taco_encode of the same handle runs
+  on another: both results equal those of the same calls made one after the other, bit for bit, every time."""
+  from tacotron_amd import _lib
+  from conftest import golden_ids
+  from test_gpu_parity import chans, dev
+  z, meta = load_golden("ljs")
+  gm = gpu_model(meta["scenario"], meta["gate"])
+  L = _lib.lib()
+  ids = golden_ids(z)
+  enc_in = ([dev(c) for c in chans(ids)], dev(ids["speakers"]), None)
+  g = torch.Generator().manual_seed(11)
+  B, T_cap = 1, 250                      # 250 frames: every layer's tiles are shared by several workgroups (partial tiles in use)
+  mel = torch.randn(B, gm.dims.n_mel, T_cap, generator=g).to("cuda:0")
+  nf = torch.tensor([T_cap], dtype=torch.int32, device="cuda:0")
+  mem_want, pm_want = gm.encode(*enc_in)
+  post_want = _postnet(gm, L.taco_postnet_noalloc, mel, nf)
+  torch.cuda.synchronize()
+  side = torch.cuda.Stream(device="cuda:0")
+  for _ in range(20):
+    out = torch.full_like(mel, float("nan"))
+    with torch.cuda.stream(side):
+      _lib.check(L.taco_postnet_noalloc(gm._require(), C.c_void_p(mel.data_ptr()), C.c_void_p(nf.data_ptr()), B, T_cap,
+                                        C.c_void_p(out.data_ptr()), C.c_void_p(side.cuda_stream)))
+    mem, pm = gm.encode(*enc_in)
+    torch.cuda.synchronize()
+    assert torch.equal(out, post_want)
+    assert torch.equal(mem, mem_want) and torch.equal(pm, pm_want)

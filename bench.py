@@ -85,6 +85,23 @@ def cpu_baseline(ckpt, sym, st, spk, target_s):
               ms_per_frame=round(dt / frames * 1e3, 4))
 
 
+def spawn_ranks(n):
+  """`python bench.py --gpus N` without a launcher: N ranks under torch.distributed.run as a child process (nothing in
+  this process has touched the GPU), same arguments, rank 0's JSON line relayed on stdout."""
+  import socket
+  import subprocess
+  with socket.socket() as sock:
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+  cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+         "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+  child = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True)
+  for line in child.stdout:
+    sys.stdout.write(line)
+    sys.stdout.flush()
+  sys.exit(child.wait())
+
+
 def timed_region(steps, step, barrier, max_over_ranks):
   """EXACTLY `steps` steps between two barriers; returns the slowest rank's seconds."""
   barrier()
@@ -130,17 +147,28 @@ def rehearse(args, world, rank):
   for _ in range(args.warmup):
     time.sleep(step_s)
   elapsed = timed_region(args.steps, lambda: time.sleep(step_s), barrier, max_over_ranks)
+  value = world * args.steps * args.frames / elapsed
+  out = {"rehearsal": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+         "lines": n_lines, "lines_covered_once": covered, "rank0_lines": len(mine),
+         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "value": round(value, 1)}
+  if world > 1:
+    # the one-GPU figure of the same workload, measured in the same run on every rank (here: everybody sleeps rank 0's step)
+    one_s = 0.002
+    for _ in range(args.warmup):
+      time.sleep(one_s)
+    elapsed1 = timed_region(args.steps, lambda: time.sleep(one_s), barrier, max_over_ranks)
+    one_gpu = args.steps * args.frames / elapsed1
+    out["one_gpu_same_workload"] = {"value": round(one_gpu, 1), "ms_per_step": round(elapsed1 / args.steps * 1e3, 4)}
+    out["efficiency"] = round(value / (world * one_gpu), 4)
+  out["cpu_baseline"] = {"rehearsal": True, "rank": rank} if rank == 0 else None
+  barrier()
   if rank == 0:
-    print(json.dumps({"rehearsal": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                      "lines": n_lines, "lines_covered_once": covered, "rank0_lines": len(mine),
-                      "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-                      "value": round(world * args.steps * args.frames / elapsed, 1)}), flush=True)
+    print(json.dumps(out), flush=True)
   if dist is not None:
     dist.destroy_process_group()
 
 
 MFMA_F32_PEAK_TFLOPS = 157.3   # dense f32-input matrix-core peak (v_mfma_f32_16x16x4_f32 / 32x32x2_f32)
-HOP_US = 0.9                   # one cross-CU hand-off of a short vector, store to consumed (0.8 - 1.0 us measured, scripts/hop_bench.hip)
 HOPS_PER_FRAME = 5             # dh -> h1 -> p -> ah -> energy partials -> dh (taco_decoder.hip)
 
 
@@ -148,6 +176,21 @@ def latest_profile(pattern):
   import glob
   found = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
   return found[-1] if found else None
+
+
+def hop_cost():
+  """The cost of one dependent cross-CU hand-off of a short vector (a small group of workgroups publishes, all 256
+  consume, store to consumed), as the stand-alone microbenchmark measured it on this part: read from the newest
+  profiles/r*_hop.json (written by scripts/micro_summary.py from the output of scripts/hop_probe.hip).  Returns
+  (microseconds, file) or (None, None) when no such file is there."""
+  src = latest_profile("r*_hop.json")
+  if not src:
+    return None, None
+  try:
+    with open(src) as f:
+      return float(json.load(f)["hop_us"]), os.path.relpath(src, ROOT)
+  except (OSError, KeyError, TypeError, ValueError):
+    return None, None
 
 
 def flops_per_frame(d, T_in):
@@ -167,7 +210,7 @@ def batch64_bf16_record(model, ckpt, device, fp32_record, frames=600, reps=3):
   reference's under teacher forcing (tests/test_gpu_parity.py), not within the fp32 bound."""
   model.set_precision("bf16")
   try:
-    r = batch64_record(model, ckpt, device, frames, reps)
+    r = batch64_record(model, ckpt, device, frames, reps, pmc_pattern="r*_bf16_lockstep_pmc.json")
   finally:
     model.set_precision("fp32")
   roof = r["roofline"]
@@ -180,12 +223,12 @@ def batch64_bf16_record(model, ckpt, device, fp32_record, frames=600, reps=3):
           "roofline": {"bound": "mfma", "achieved": roof["achieved"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                        "frac": round(roof["achieved"] / MFMA_BF16_PEAK_TFLOPS, 4), "kernel": "taco_decoder_batch_kernel<bf16>",
                        "kernel_ms_per_launch": roof["kernel_ms_per_launch"], "flops_per_launch": roof["flops_per_launch"],
-                       "traffic": None,
+                       "traffic": roof["traffic"], "traffic_source": roof["traffic_source"], "counters": roof["counters"],
                        "note": "same algorithmic FLOPs as the fp32 launch; in this setting the matrix cores are nowhere near "
                                "their bound - the frame is the chain of six dependent exchanges between the CUs"}}
 
 
-def batch64_record(model, ckpt, device, frames=600, reps=3):
+def batch64_record(model, ckpt, device, frames=600, reps=3, pmc_pattern="r*[0-9a-z]_lockstep_pmc.json"):
   """The batched configuration: 64 synthetic lines (40..160 symbols, generator seed 2024, longest first) in one padded batch,
   every line run to `frames` decoder steps: encode + lockstep decoder (one persistent launch, 16 utterances in flight) + postnet."""
   from tacotron_amd import scenarios
@@ -221,7 +264,11 @@ def batch64_record(model, ckpt, device, frames=600, reps=3):
   per_utt = [t * (d_.A + d_.M) * 4 + (2 * d_.R_a + 2 * d_.R_d + d_.M + d_.P + d_.n_mel + 1 + 2 * t) * 4 for t in lens]
   lockstep_frames = 64 * frames // 16
   alg_bytes = model.step_weight_bytes * lockstep_frames + sum(per_utt) * frames
-  counters, traffic, src = None, None, latest_profile("r*_lockstep_pmc.json")
+  import glob
+  # (the fp32 setting's counter files are r<tag>_lockstep_pmc.json, the bf16 setting's r<tag>_bf16_lockstep_pmc.json)
+  found = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", pmc_pattern))
+                 if ("_bf16_" in os.path.basename(f)) == ("_bf16_" in pmc_pattern))
+  counters, traffic, src = None, None, (found[-1] if found else None)
   if src:
     prof = json.load(open(src))["derived"]
     counters = {"source": os.path.relpath(src, ROOT),
@@ -229,7 +276,9 @@ def batch64_record(model, ckpt, device, frames=600, reps=3):
                 "mfma_instructions_per_lockstep_frame": prof.get("SQ_INSTS_VALU_MFMA_F32_per_lockstep_frame"),
                 "issue_fraction_of_wave_cycles": prof.get("SQ_ACTIVE_INST_ANY_per_WAVE_CYCLE"),
                 "valu_issue_fraction": prof.get("SQ_ACTIVE_INST_VALU_per_WAVE_CYCLE"),
-                "scalar_issue_fraction": prof.get("SQ_ACTIVE_INST_SCA_per_WAVE_CYCLE")}
+                "scalar_issue_fraction": prof.get("SQ_ACTIVE_INST_SCA_per_WAVE_CYCLE"),
+                "wait_fraction_of_wave_cycles": prof.get("SQ_WAIT_INST_ANY_per_WAVE_CYCLE"),
+                "lds_bank_conflict_fraction": prof.get("lds_bank_conflict_cycles_per_active_cycle")}
     if prof.get("hbm_bytes_per_lockstep_frame"):
       traffic = int(prof["hbm_bytes_per_lockstep_frame"]) * (64 * frames // 16)
   return {"workload": f"64 lines of {min(lens)}..{max(lens)} symbols in one padded batch, {frames} frames each, lockstep decoder "
@@ -248,9 +297,10 @@ def batch64_record(model, ckpt, device, frames=600, reps=3):
                                "the launch stream); exact-f32 matrix-core products run at the f32 vector rate, 1/16 of the bf16 rate"}}
 
 
-def lines_workload(model, ckpt, device, world, rank, lines_per_gpu, frames, batch_size):
+def lines_workload(model, ckpt, device, world, rank, lines_per_gpu, frames, batch_size, live_stop=False):
   """The batch-synthesis configuration: world x lines_per_gpu synthetic lines, LPT-sharded over the ranks; returns
-  (step function, frames of this rank per step, description)."""
+  (step function, frames of this rank per step, frames of the job per step, description).  live_stop: the stop test
+  decides (a checkpoint with a calibrated stop token; the step function then returns the frames it produced)."""
   from tacotron_amd import scenarios, sharding
   from tacotron_amd.masks import prenet_keep_masks
   n_lines = world * lines_per_gpu
@@ -267,14 +317,18 @@ def lines_workload(model, ckpt, device, world, rank, lines_per_gpu, frames, batc
                     d(ids["speakers"]), d(ids["lens"])))
 
   def step():
-    out = None
+    out, counts = None, []
     for chans, spk, ln in batches:
       mem, pm = model.encode(chans, spk, ln)
-      mel, gate, align, nf, reached = model.decode(mem, pm, ln, masks, frames, gate_threshold=2.0, want_align=False)
+      mel, gate, align, nf, reached = model.decode(mem, pm, ln, masks, frames, gate_threshold=None if live_stop else 2.0,
+                                                   want_align=False)
       out = model.postnet(mel, nf)
-    return out
+      counts.append(nf)
+    return int(torch.cat(counts).sum()) if live_stop else out
 
-  desc = (f"{n_lines} synthetic lines (T_in ~ U{{20..200}}, seed 2024), {frames} decoder frames each (stop disabled), "
+  desc = (f"{n_lines} synthetic lines (T_in ~ U{{20..200}}, seed 2024), "
+          + (f"stop test live (calibrated stop token), at most {frames} decoder frames each, " if live_stop else
+             f"{frames} decoder frames each (stop disabled), ") +
           f"partitioned longest-processing-time-first over {world} rank(s), padded batches of {batch_size} "
           "(lockstep decoder, one persistent launch per batch, 16 utterances in flight), encoder + decoder + postnet")
   return step, len(mine) * frames, n_lines * frames, desc
@@ -298,13 +352,14 @@ def main():
                        "(the printed line is marked rehearsal and is not a measurement)")
   args = ap.parse_args()
 
+  if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+    # started plainly: this process has made no GPU call yet and makes none - it starts the N ranks as children
+    # (torch.distributed.run, one process per GPU), passes their output through and ends with their exit status
+    return spawn_ranks(args.gpus)
   world = int(os.environ.get("WORLD_SIZE", "1"))
   rank = int(os.environ.get("RANK", "0"))
   local_rank = int(os.environ.get("LOCAL_RANK", "0"))
   if world != args.gpus:
-    if world == 1 and args.gpus > 1:
-      raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                       "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
     raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
   if args.rehearse_ranks:
     return rehearse(args, world, rank)
@@ -370,14 +425,35 @@ def main():
       "real_time_factor": round(args.steps * audio_s / elapsed, 1),
       "rank0_frames_per_s": round(my_frames / float(np.mean(rank_s)), 1),
       "per_gpu_frames_per_s": round(value / world, 1),
-      "note": "one GPU runs workload b1 by default (batch-1 latency, the headline configuration); the one-GPU figure of THIS workload is "
-              "`lines_one_gpu.value` of that run's line (= `--workload lines`): weak-scaling efficiency = value / (n_gpus x that)",
     }
+    if world > 1:
+      # The same workload on ONE GPU, measured in this run: every rank decodes the one-rank line set (lines_per_gpu lines,
+      # what `--gpus 1 --workload lines` runs) on its own GPU, same warm-up and step counts; the slowest rank's time counts.
+      # efficiency = value / (n_gpus x that figure).  (The default one-GPU run, `--gpus 1`, is another workload - batch 1,
+      # the headline configuration - and its value is NOT the denominator of this one.)
+      step1, _, job1, desc1 = lines_workload(model, ckpt, device, 1, 0, args.lines_per_gpu, frames, args.batch_size)
+      for _ in range(args.warmup):
+        step1()
+      elapsed1 = timed_region(args.steps, lambda: (step1(), torch.cuda.synchronize(device)), barrier, max_over_ranks)
+      one_gpu = job1 * args.steps / elapsed1
+      out["one_gpu_same_workload"] = {"workload": desc1, "value": round(one_gpu, 1), "unit": "mel frames/s",
+                                      "ms_per_step": round(elapsed1 / args.steps * 1e3, 4), "steps": args.steps, "warmup": args.warmup,
+                                      "note": "measured in this run on every rank's GPU at once (slowest rank), no sharding"}
+      out["efficiency"] = round(value / (world * one_gpu), 4)
+      out["note"] = ("weak scaling of the sharded line set: efficiency = value / (n_gpus x one_gpu_same_workload.value), both measured in "
+                     "this run.  `python bench.py --gpus 1` runs the batch-1 headline configuration, a different workload: its value "
+                     "must not be used as this curve's one-GPU point (its line carries `lines_one_gpu` for that purpose)")
     # the dominant kernel's roofline: measured on this rank's GPU outside the timed region (every rank does the same
-    # work, rank 0's figures are printed); the CPU baseline belongs to the one-GPU run of workload b1
+    # work, rank 0's figures are printed)
     out["batch64"] = batch64_record(model, ckpt, device)
     out["roofline"] = out["batch64"]["roofline"]
     out["cpu_baseline"] = None
+    if rank == 0 and args.cpu_seconds > 0:
+      # rank 0 only, while the other ranks wait at the closing barrier
+      sym, st, spk = build_inputs(ckpt)
+      out["cpu_baseline"] = cpu_baseline(ckpt, sym, st, spk, args.cpu_seconds)
+      out["cpu_baseline"]["sample"] += "; per frame the port's cost does not depend on how lines are batched"
+    barrier()
     if rank == 0:
       print(json.dumps(out), flush=True)
     if dist is not None:
@@ -453,7 +529,8 @@ def main():
                 "lds_frac": round(lds_gbs / 150000.0, 4)}
   except (TypeError, OSError, KeyError, ValueError):
     counters = None
-  floor_us = HOPS_PER_FRAME * HOP_US
+  hop_us, hop_source = hop_cost()
+  floor_us = HOPS_PER_FRAME * hop_us if hop_us else None
   out = {
     "metric": "mel frames/sec", "value": round(value, 1), "unit": "mel frames/s", "n_gpus": world,
     "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -464,17 +541,18 @@ def main():
     "real_time_factor": round(world * args.steps * audio_s / elapsed, 1),
     "decoder_us_per_frame": round(us_per_frame, 3),
     "decoder_step_latency_us": step_latency,
-    "roofline": {"bound": "handoff-latency", "achieved": round(us_per_frame, 3), "peak": round(floor_us, 3), "unit": "us/frame",
-                 "frac": round(floor_us / us_per_frame, 4), "traffic": traffic, "traffic_source": traffic_source,
+    "roofline": {"bound": "handoff-latency", "achieved": round(us_per_frame, 3), "peak": floor_us and round(floor_us, 3), "unit": "us/frame",
+                 "frac": floor_us and round(floor_us / us_per_frame, 4), "traffic": traffic, "traffic_source": traffic_source,
                  "kernel": "taco_decoder_kernel", "kernel_ms_per_launch": round(dec_s * 1e3, 4),
-                 "hops_per_frame": HOPS_PER_FRAME, "hop_us": HOP_US,
+                 "hops_per_frame": HOPS_PER_FRAME, "hop_us": hop_us, "hop_source": hop_source,
                  "residency_ratio": round(streaming / HBM_PEAK_GBS, 4),
                  "hbm_streaming": {"bytes_per_frame": int(bytes_per_frame), "achieved_gbs": round(streaming, 1),
                                    "peak_gbs": HBM_PEAK_GBS},
                  "counters": counters,
                  "note": "batch 1: the LSTM rows are register-resident (residency_ratio = algorithmic bytes per frame / time over "
                          "the HBM peak; above 1 = faster than streaming the weights from HBM could be), so the bound that applies "
-                         "is the chain of dependent cross-CU hand-offs: frac = (hops x cost of one hop) / measured frame time"},
+                         "is the chain of dependent cross-CU hand-offs: frac = (hops x cost of one hop, as the stand-alone microbenchmark "
+                         "behind hop_source measured it) / measured frame time"},
   }
   if rank == 0 and world == 1:
     out["batch64"] = batch64_record(model, ckpt, device)
@@ -492,6 +570,27 @@ def main():
     out["lines_one_gpu"] = {"workload": ldesc, "value": round(ljob / lsec, 1), "unit": "mel frames/s",
                             "ms_per_step": round(lsec * 1e3, 3), "steps": 3,
                             "note": "same as `python bench.py --workload lines`; runs with --gpus N > 1 measure this workload"}
+    # ... and the same lines with the stop test deciding (the calibrated stop token of the parity tests' checkpoint):
+    # utterances end at different frames, slots refill, every call ends with a drain
+    try:
+      with open(os.path.join(ROOT, "tests", "golden", "gate_bias.json")) as f:
+        ckpt_stop = scenarios.checkpoint("ljs", json.load(f)["ljs"])
+      model_stop = Tacotron2(hp, **abi.mapping_counts(ckpt_stop, hp))
+      model_stop.load_state_dict(ckpt_stop["model_state"])
+      model_stop.to(device)
+      sstep, _, _, sdesc = lines_workload(model_stop, ckpt_stop, device, 1, 0, args.lines_per_gpu, frames, args.batch_size,
+                                          live_stop=True)
+      sstep()
+      torch.cuda.synchronize(device)
+      t0 = time.perf_counter()
+      produced = sum(sstep() for _ in range(3))
+      torch.cuda.synchronize(device)
+      ssec = time.perf_counter() - t0
+      out["lines_one_gpu_live_stop"] = {"workload": sdesc, "value": round(produced / ssec, 1), "unit": "mel frames/s",
+                                        "frames_per_step": produced // 3, "ms_per_step": round(ssec / 3 * 1e3, 3), "steps": 3}
+      model_stop.close()
+    except (OSError, KeyError, ValueError) as ex:
+      out["lines_one_gpu_live_stop"] = {"skipped": str(ex)}
   if rank == 0 and world == 1 and args.cpu_seconds > 0:
     out["cpu_baseline"] = cpu_baseline(ckpt, sym, st, spk, args.cpu_seconds)
     try:

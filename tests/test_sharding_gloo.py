@@ -117,3 +117,26 @@ def test_bench_rank_plumbing_rehearsal():
   # the sharded line set of the multi-GPU workload: every line in exactly one rank's shard, shards of equal size here
   assert out["lines"] == 512 and out["lines_covered_once"] is True and 200 <= out["rank0_lines"] <= 312
   assert out["ms_per_step"] >= 4.0          # rank 1 sleeps 4 ms per step, rank 0 only 2 ms
+  # the one-GPU figure of the same workload and the efficiency against it come out of the same run
+  assert out["one_gpu_same_workload"]["ms_per_step"] >= 2.0
+  assert 0.3 < out["efficiency"] < 0.7      # 2 ranks, the slower at half speed: about 0.5
+  assert out["cpu_baseline"] is not None
+
+
+def test_bench_started_plainly_spawns_its_ranks():
+  """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE (how a driver may start it): the process starts
+  the two ranks itself as children, before anything touches a GPU, and relays rank 0's one JSON line."""
+  import json
+  env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+  env.update(OMP_NUM_THREADS="1", PYTHONPATH=ROOT)
+  cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--rehearse-ranks"]
+  res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=180)
+  assert res.returncode == 0, res.stdout + res.stderr
+  lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+  assert len(lines) == 1
+  out = json.loads(lines[0])
+  assert out["n_gpus"] == 2 and out["steps"] == 4 and out["rehearsal"] is True
+  assert out["lines_covered_once"] is True and "efficiency" in out
+  # a wrong launch is still refused: --gpus must agree with the launcher's world size
+  bad = subprocess.run(cmd, env=dict(env, WORLD_SIZE="3", RANK="0"), capture_output=True, text=True, timeout=60)
+  assert bad.returncode != 0 and "WORLD_SIZE" in (bad.stdout + bad.stderr)

@@ -151,10 +151,18 @@ __global__ __launch_bounds__(256) void taco_conv_kernel(const float* __restrict_
     };
     auto store_item = [&](int it, int buf, const float (&pw)[NW], const float (&px)[XR][NX]) {
       if (it < SW) {
+#ifdef CV_FAKE_WW
+        *reinterpret_cast<float2*>(&ws[buf][0][(tid * 2 + 512 * it) % (CV_CO * WS - 2)]) = make_float2(pw[2 * it], pw[2 * it + 1]);
+#else
         *reinterpret_cast<float2*>(&ws[buf][srow][seg * NW + 2 * it]) = make_float2(pw[2 * it], pw[2 * it + 1]);
+#endif
       } else {
         const int q = (it - SW) / NX, n = (it - SW) % NX;
+#ifdef CV_FAKE_XW
+        if (seg + 8 * n < XW) xs[buf][0][(tid + 256 * (q * NX + n)) % (CI * XS)] = px[q][n];
+#else
         if (seg + 8 * n < XW) xs[buf][srow + 32 * q][seg + 8 * n] = px[q][n];
+#endif
       }
     };
     const int n_slabs_all = (c_in + CI - 1) / CI;

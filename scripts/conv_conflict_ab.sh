@@ -1,7 +1,8 @@
 #!/bin/bash
 # Where the convolution kernel's LDS bank conflicts come from and what they cost: the product library against timing-only
-# builds whose staging writes go to conflict-free (wrong) addresses (-DCV_FAKE_WW weights, -DCV_FAKE_XW inputs; built by
-# hand into build_diag/libtaco_cv_{ww,xw,both}.so).  Per build: the postnet's time at 38400 columns and one counter pass
+# builds whose staging writes go to conflict-free (wrong) addresses (weights: ws[buf][0][(tid * 2 + 512 * it) % ...], inputs:
+# xs[buf][0][(tid + 256 * item) % ...], two three-line edits of store_item in taco_layers.hip as it was before the inputs'
+# row-per-instruction map; built by hand into build_diag/libtaco_cv_{ww,xw,both}.so).  Per build: the postnet's time at 38400 columns and one counter pass
 # (SQ_LDS_BANK_CONFLICT, SQ_LDS_IDX_ACTIVE).  Run from the repository root: bash scripts/conv_conflict_ab.sh <tag>
 set -e
 tag=${1:?tag}

@@ -82,18 +82,24 @@ __global__ __launch_bounds__(256) void taco_conv_kernel(const float* __restrict_
   constexpr int CI = taco_conv_ci(KS);         // input channels per slab
   constexpr int PAD = (KS - 1) / 2;
   constexpr int XW = CV_TT + KS - 1;           // input columns a tile needs
-  constexpr int XS = CV_XS;                    // row stride = 32 (mod 64): the two k-lanes of an MFMA hit disjoint banks
-  constexpr int WS = CI * KS + 2;              // row stride = 2 or 34 (mod 64): the 32 rows of a k-lane fall on the 32 even banks, the
-                                               // other k-lane's (an odd number of floats further) on the odd ones; even, so that a
-                                               // thread's staged weights go to LDS as 8-byte writes
+  constexpr int XS = CV_XS;                    // (a B-operand read: the 32 lanes of a half wave take 32 consecutive words - conflict-free)
+  constexpr int WS = CI * KS + 2;              // even row stride, so that a thread's staged weights go to LDS as 8-byte writes.  A
+                                               // ds_read_b32 is banked by word address mod 32 within each half wave, so the 32 rows
+                                               // of a k-lane meet two to a bank (one extra LDS cycle per A-operand read); an odd
+                                               // stride (conflict-free reads and writes, built and measured) needs twice the write
+                                               // instructions and came out 4 % slower: the slab loop waits for issue slots, not
+                                               // for the LDS array
   constexpr int RL = CI * KS;                  // weights of one output channel in a slab: contiguous in memory
   constexpr int NW = RL / 8;                   // 8 threads per weight row, NW consecutive floats each
-  constexpr int NX = (XW + 7) / 8;             // 8 threads per input row, columns seg, seg + 8, ...
-  static_assert(XW <= XS && 2 * CV_CO * WS >= 2 * 16 * 64 && RL % 32 == 0 && CI * 8 == 256 * (CI / 32) && NW % 2 == 0 && (2 * CI * XS) % 2 == 0, "tile geometry");
+  constexpr int HW = XW - CV_TT;               // halo columns of an input row beyond the first 64 (KS - 1)
+  constexpr bool ROWMAP = !IN_TM;              // input staging map, see below
+  constexpr int NX = (XW + 7) / 8, XR = CI / 32; // (position-major inputs: 8 threads per input row, columns seg, seg + 8, ...)
+  constexpr int NXI = ROWMAP ? CI / 4 + (HW > 0 ? 1 : 0) : XR * NX;   // input words per thread and slab
+  static_assert(XW <= XS && 2 * CV_CO * WS >= 2 * 16 * 64 && RL % 32 == 0 && CI * 8 == 256 * (CI / 32) && NW % 2 == 0 && (2 * CI * XS) % 2 == 0 && CI * HW <= 256, "tile geometry");
   extern __shared__ __attribute__((aligned(16))) float conv_lds[];
   float (*xs)[CI][XS] = reinterpret_cast<float (*)[CI][XS]>(conv_lds);                       // [2][CI][XS]
   float (*ws)[CV_CO][WS] = reinterpret_cast<float (*)[CV_CO][WS]>(conv_lds + 2 * CI * XS);   // [2][CV_CO][WS]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int thalf = wave & 1, khalf = wave >> 1;
   const int i = lane & 31, h = lane >> 5;
   const int b = blockIdx.z;
@@ -110,15 +116,18 @@ __global__ __launch_bounds__(256) void taco_conv_kernel(const float* __restrict_
   for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 
   if (t0 < len) {
-    // Staging map: thread = (row tid >> 3, segment tid & 7).  Weights: row = output channel, the thread takes NW
-    // consecutive floats of the slab's RL (16-byte loads).  Inputs: CI / 32 rows per thread (row + 32 q), columns
-    // seg + 8 n.  Both come through buffer loads, whose out-of-range offsets return zero: a padding position, a column
+    // Staging map.  Weights: thread = (row tid >> 3, segment tid & 7), row = output channel, the thread takes NW
+    // consecutive floats of the slab's RL (16-byte loads).  Inputs, channel-major: wave w takes rows w * CI / 4 + j,
+    // lane = column (the 64 lanes of a load or an LDS write cover 64 consecutive words: whole cache lines, 32 distinct
+    // banks per half wave), and the HW halo columns of all CI rows are one more word for thread (row tid / HW, column
+    // 64 + tid % HW).  Inputs, position-major (memory runs along the channels): thread (row tid >> 3, segment tid & 7)
+    // takes CI / 32 rows (row + 32 q), columns seg + 8 n.
+    // Both come through buffer loads, whose out-of-range offsets return zero: a padding position, a column
     // past the utterance, an input channel past c_in or a weight row past c_out is simply given the offset ~0 (no
     // branch, no 64-bit address arithmetic, nothing read that is not there).  A ragged last slab's weight loads run on
     // into the next row's weights - finite values that meet input rows staged as zeros.
-    constexpr int XR = CI / 32;
-    constexpr int LW = NW / 4, LX = XR * NX;     // load items of a slab per thread: 16-byte weight loads, input words
-    constexpr int SW = NW / 2, SX = XR * NX;     // store items: 8-byte weight writes, input words
+    constexpr int LW = NW / 4, LX = NXI;         // load items of a slab per thread: 16-byte weight loads, input words
+    constexpr int SW = NW / 2, SX = NXI;         // store items: 8-byte weight writes, input words
     constexpr int ITEMS = LW + LX + SW + SX;
     constexpr int MFMAS = KS * (CI / 4);         // matrix-core products of a slab per wave
     constexpr unsigned OOB = 0xffffffffu;
@@ -127,42 +136,51 @@ __global__ __launch_bounds__(256) void taco_conv_kernel(const float* __restrict_
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, (int)((unsigned)c_out * (unsigned)c_in * KS * 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)in_b, 0, (int)((unsigned)c_in * (unsigned)T * 4u), 0x00020000);
     const unsigned w_off = co0 + srow < c_out ? ((unsigned)(co0 + srow) * (unsigned)c_in * KS + (unsigned)(seg * NW)) * 4u : OOB;
-    unsigned col_off[NX];                        // byte offset of my column n inside a row (channel-major) / of its row (position-major)
+    // byte offset of my column inside a row (channel-major) / of its row (position-major): main part, halo part
+    const int hrow = HW > 0 ? tid / (HW > 0 ? HW : 1) : CI, hcol = HW > 0 ? CV_TT + tid % (HW > 0 ? HW : 1) : 0;
+    unsigned col_off[ROWMAP ? 2 : NX];
 #pragma unroll
-    for (int n = 0; n < NX; ++n) {
-      const int c = seg + 8 * n, tt = t0 + c - PAD;
-      col_off[n] = (c < XW && tt >= 0 && tt < len) ? (unsigned)tt * (in_time_major ? (unsigned)c_in : 1u) * 4u : OOB;
+    for (int n = 0; n < (ROWMAP ? 2 : NX); ++n) {
+      const int c = ROWMAP ? (n == 0 ? lane : hcol) : seg + 8 * n, tt = t0 + c - PAD;
+      const bool mine = ROWMAP ? (n == 0 || hrow < CI) : c < XW;
+      col_off[n] = (mine && tt >= 0 && tt < len) ? (unsigned)tt * (in_time_major ? (unsigned)c_in : 1u) * 4u : OOB;
     }
-    float pwA[NW], pxA[XR][NX], pwB[NW], pxB[XR][NX];
+    float pwA[NW], pxA[NXI], pwB[NW], pxB[NXI];
     // item `it` of the loads of the slab that starts at input channel ci0
-    auto load_item = [&](int it, int ci0, float (&pw)[NW], float (&px)[XR][NX]) {
+    auto load_item = [&](int it, int ci0, float (&pw)[NW], float (&px)[NXI]) {
       if (it < LW) {
         const unsigned off = w_off == OOB ? OOB : w_off + (unsigned)(ci0 * KS + 4 * it) * 4u;
         const taco_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_w, off, 0, 0);
         pw[4 * it] = __uint_as_float(v.x); pw[4 * it + 1] = __uint_as_float(v.y);
         pw[4 * it + 2] = __uint_as_float(v.z); pw[4 * it + 3] = __uint_as_float(v.w);
       } else {
-        const int q = (it - LW) / NX, n = (it - LW) % NX;
-        const int ci = ci0 + srow + 32 * q;
-        const unsigned row = (unsigned)ci * (in_time_major ? 1u : (unsigned)T) * 4u;
-        const unsigned off = (col_off[n] != OOB && ci < c_in) ? col_off[n] + row : OOB;
-        px[q][n] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_x, off, 0, 0));
+        const int j = it - LW;
+        if constexpr (ROWMAP) {
+          const bool halo = j >= CI / 4;
+          const int ci = ci0 + (halo ? hrow : wave * (CI / 4) + j);
+          const unsigned coff = col_off[halo ? 1 : 0];
+          const unsigned off = (coff != OOB && ci < c_in) ? coff + (unsigned)ci * (unsigned)T * 4u : OOB;
+          px[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_x, off, 0, 0));
+        } else {
+          const int q = j / NX, n = j % NX;
+          const int ci = ci0 + srow + 32 * q;
+          const unsigned off = (col_off[n] != OOB && ci < c_in) ? col_off[n] + (unsigned)ci * 4u : OOB;
+          px[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_x, off, 0, 0));
+        }
       }
     };
-    auto store_item = [&](int it, int buf, const float (&pw)[NW], const float (&px)[XR][NX]) {
+    auto store_item = [&](int it, int buf, const float (&pw)[NW], const float (&px)[NXI]) {
       if (it < SW) {
-#ifdef CV_FAKE_WW
-        *reinterpret_cast<float2*>(&ws[buf][0][(tid * 2 + 512 * it) % (CV_CO * WS - 2)]) = make_float2(pw[2 * it], pw[2 * it + 1]);
-#else
         *reinterpret_cast<float2*>(&ws[buf][srow][seg * NW + 2 * it]) = make_float2(pw[2 * it], pw[2 * it + 1]);
-#endif
       } else {
-        const int q = (it - SW) / NX, n = (it - SW) % NX;
-#ifdef CV_FAKE_XW
-        if (seg + 8 * n < XW) xs[buf][0][(tid + 256 * (q * NX + n)) % (CI * XS)] = px[q][n];
-#else
-        if (seg + 8 * n < XW) xs[buf][srow + 32 * q][seg + 8 * n] = px[q][n];
-#endif
+        const int j = it - SW;
+        if constexpr (ROWMAP) {
+          if (j < CI / 4) xs[buf][wave * (CI / 4) + j][lane] = px[j];
+          else if (hrow < CI) xs[buf][hrow][hcol] = px[j];
+        } else {
+          const int q = j / NX, n = j % NX;
+          if (seg + 8 * n < XW) xs[buf][srow + 32 * q][seg + 8 * n] = px[j];
+        }
       }
     };
     const int n_slabs_all = (c_in + CI - 1) / CI;
@@ -174,7 +192,7 @@ __global__ __launch_bounds__(256) void taco_conv_kernel(const float* __restrict_
     // runs in the first one's shadow, whatever is bunched up behind the last one does not.  So the slab's staging work
     // - the operand reads of the next step, the global loads, the LDS writes - is dealt out one or two instructions at
     // a time behind each product, and scheduling barriers keep the compiler from gathering it up again.
-    auto slab = [&](int s, float (&fw)[NW], float (&fx)[XR][NX], const float (&kw)[NW], const float (&kx)[XR][NX]) {
+    auto slab = [&](int s, float (&fw)[NW], float (&fx)[NXI], const float (&kw)[NW], const float (&kx)[NXI]) {
       const int buf = s & 1;
       const int ci_next = (sl0 + min(s + 2, n_slabs - 1)) * CI;     // past the end: a harmless reload of the last slab
       float av[2][KS], bv[2][KS];

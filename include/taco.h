@@ -145,8 +145,9 @@ int taco_encode(taco_handle h, const int64_t* const* ids, const int64_t* speaker
  * Utterances of up to 224 symbols go through the lockstep kernel: ONE launch advances sixteen of them frame by frame
  * (their LSTM gate rows as matrix-core tiles), and when one stops the next utterance of the call takes its slot, so
  * a large B keeps all sixteen slots busy; an utterance's result there is bit-identical whatever else is in the call.
- * Longer utterances, and an utterance left alone, each get a launch of the batch-1 kernel (same results to 1e-4
- * under teacher forcing).  The launches of one call run back to back on `stream`.
+ * Longer utterances (up to 1024 symbols; T_in beyond that returns TACO_EINVAL), and an utterance left alone, each get a
+ * launch of the batch-1 kernel (same results to 1e-4 under teacher forcing).  The launches of one call run back to back
+ * on `stream`.
  * Environment: TACO_DECODER=single or =lockstep forces one kernel.
  * Replaces Decoder.inference (reference: src/tacotron/model.py:529-568, 454-491, 96-117, 136-141).
  *   memory, processed_memory, lens   as produced by / passed to taco_encode

@@ -60,14 +60,20 @@
 
 namespace {
 
+#ifndef TACO_Q_POS
+#define TACO_Q_POS 64          // positions per Q workgroup
+#endif
 constexpr int NT = TACO_DEC_THREADS;
 constexpr int NW = NT / 64;                          // waves per workgroup
 // The context part of an LSTM row holds the row's folded context weights G[row][s], one column per
 // input position: NMF chunks cover TACO_MAX_TIN positions.
 constexpr int NMF = 2;
-static_assert(NMF * TACO_CHUNK == TACO_MAX_TIN, "folded context chunks must cover the position capacity");
+static_assert(NMF * TACO_CHUNK == TACO_FOLD_TIN, "folded context chunks must cover the positions kept on chip");
 // A kernel instance holds NCTX <= NMF of them in registers: utterances of up to 256 positions run the
-// instance with one chunk, which leaves 16 registers per lane to the rest of the frame.
+// instance with one chunk, which leaves 16 registers per lane to the rest of the frame.  Utterances of more than
+// NMF * 256 positions run the LONG instance: one chunk in registers, the columns of the other positions read from
+// global memory (L2) every frame - slower per frame, but no input is refused for its length up to TACO_MAX_TIN.
+constexpr int NPOS_LONG = TACO_MAX_TIN / TACO_DEC_THREADS;     // positions per thread in the softmax of the LONG instance
 constexpr int HALO = 16;                            // >= (K-1)/2 zero columns around the weights
 constexpr int PW = TACO_NP * TACO_CHUNK;            // prenet width capacity (256)
 constexpr int QD = TACO_MAX_A / TACO_NQ_WG;         // attention dimensions per Q workgroup (16)
@@ -88,7 +94,7 @@ constexpr int L_BIAS = L_CELLS + 8;                            // b_ih + b_hh of
 constexpr int L_GATE_IN = L_BIAS + 32;                         // stop token of the previous frame, failure flag [4]
 constexpr int L_X = L_GATE_IN + 4;                             // unnormalised attention weights of this frame
 constexpr int L_ROLE = L_X + TACO_MAX_TIN;
-static_assert(TACO_MAX_TIN == NT, "the softmax takes one position per thread");
+static_assert(TACO_FOLD_TIN == NT && TACO_MAX_TIN % NT == 0, "the softmax takes one position per thread (LONG: TACO_MAX_TIN / NT)");
 // P group: per wave one row of the prenet: layer 1 folded into the projection [1024 hidden + 512 folded
 //          context] and its bias, the plain layer-1 row [128] (teacher forcing), the layer-2 row [256];
 //          the gathered layer-1 output [256]; keep bytes [2 parities][2 layers][256 B]
@@ -106,7 +112,7 @@ static_assert(TACO_MAX_MEL <= 128 && PW == 256, "prenet row capacities");
 //          the folded location filter of my dimensions
 constexpr int LQ_ROWS = L_ROLE;
 constexpr int LQ_U = LQ_ROWS + QD * TACO_NA * TACO_CHUNK;
-constexpr int LQ_V = LQ_U + QD * TACO_MAX_TIN;
+constexpr int LQ_V = LQ_U + QD * TACO_Q_POS;                    // (U is indexed by the position inside my range of TACO_Q_POS)
 constexpr int LQ_PE8 = L_PE;                                   // per-wave energy partials live where the gathered partials
                                                                 // will land (dead until then; a barrier separates the uses)
 static_assert(NW <= TACO_NQ_WG, "per-wave partials fit the gathered-partials area");
@@ -270,11 +276,12 @@ __device__ __forceinline__ float lstm_cell_lanes(const float* gates_lds, const f
 // STD = true fixes the extents of the usual checkpoint geometry (prenet 256, both LSTMs 1024, attention
 // 128 / kernel 31, 80 mel channels, 256 workgroups) at compile time: fewer live scalars and no bounds
 // arithmetic in the frame loop.  STD = false takes every extent from the arguments.
-#ifndef TACO_Q_POS
-#define TACO_Q_POS 64          // positions per Q workgroup
-#endif
-template <bool STD, int NCTX>
+template <bool STD, int NCTX, bool LONG = false>
 __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const DecArgs a) {
+  static_assert(!LONG || NCTX == 1, "the LONG instance keeps one chunk of folded context weights in registers");
+  constexpr int NPOS = LONG ? NPOS_LONG : 1;          // positions per thread in the softmax
+  constexpr int ONCHIP = NCTX * TACO_CHUNK;           // positions whose folded LSTM columns are in registers
+  constexpr int ROW_ONCHIP = LONG ? NMF * TACO_CHUNK : ONCHIP;   // ... and in the LDS rows of the P / M groups
   constexpr int CH_A = TACO_NP + NCTX + TACO_NA;    // chunks per attention-LSTM row (6 or 7)
   constexpr int CH_D = TACO_NA + NCTX + TACO_ND;    // chunks per decoder-LSTM row (9 or 10)
   const int P = STD ? 256 : a.P;
@@ -395,7 +402,7 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
   if (own_p) {
     const float* G_pre = G_proj + (size_t)(NMEL + 1) * a.T_in;                       // layer 1 x projection's folded context rows
     _Pragma("unroll 1") for (int k = lane; k < Rd; k += 64) my_wf[k] = a.wf_h[(size_t)p_row * Rd + k];
-    _Pragma("unroll 1") for (int k = lane; k < a.T_in; k += 64) my_wf[TACO_ND * TACO_CHUNK + k] = G_pre[(size_t)p_row * a.T_in + k];
+    _Pragma("unroll 1") for (int k = lane; k < min(a.T_in, NMF * TACO_CHUNK); k += 64) my_wf[TACO_ND * TACO_CHUNK + k] = G_pre[(size_t)p_row * a.T_in + k];
     _Pragma("unroll 1") for (int k = lane; k < NMEL; k += 64) lds[LP_W1R + wave * 128 + k] = a.prenet_w1[(size_t)p_row * NMEL + k];
     _Pragma("unroll 1") for (int k = lane; k < P; k += 64) lds[LP_W2 + wave * PW + k] = a.prenet_w2[(size_t)p_row * P + k];
     if (lane == 0) lds[LP_BIAS + wave] = a.wf_b[p_row];
@@ -406,7 +413,7 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
       lds[LQ_ROWS + r * (TACO_NA * TACO_CHUNK) + c] = a.query_w[(size_t)(q_base + r) * Ra + c];
     }
     if (tid < q_cnt) lds[LQ_V + tid] = a.v_w[q_base + tid];
-    if (NCTX == 1)
+    if (NCTX == 1 && !LONG)
       _Pragma("unroll 1") for (int k = tid; k < q_cnt * min(len, LQ_PM_POS); k += NT) {
         const int d = k % q_cnt, sp = k / q_cnt;
         lds[LQ_PM + d * LQ_PM_POS + sp] = a.pm[(size_t)sp * A + q_base + d];
@@ -415,7 +422,7 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
   if (own_m) {
     const float* src = m_row < NMEL ? a.proj_w + (size_t)m_row * n_hc : a.gate_w;
     _Pragma("unroll 1") for (int k = lane; k < Rd; k += 64) my_proj[k] = src[k];
-    _Pragma("unroll 1") for (int k = lane; k < a.T_in; k += 64) my_proj[TACO_ND * TACO_CHUNK + k] = G_proj[(size_t)m_row * a.T_in + k];
+    _Pragma("unroll 1") for (int k = lane; k < min(a.T_in, NMF * TACO_CHUNK); k += 64) my_proj[TACO_ND * TACO_CHUNK + k] = G_proj[(size_t)m_row * a.T_in + k];
     if (lane == 0) lds[LM_BIAS + wave] = m_row < NMEL ? a.proj_b[m_row] : a.gate_b[0];
   }
   __syncthreads();
@@ -453,7 +460,7 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
       lds[LQ_E + i] = (ck < 2 * K && (l & 15) < q_cnt) ? a.loc_fold[(size_t)dim * 2 * K + ck] : 0.0f;
     }
   }
-  constexpr int LOC_UNROLL = (STD && NCTX == 1) ? LOC_KSTEPS : 2;   // as far as the instance's registers allow without spilling
+  constexpr int LOC_UNROLL = (STD && NCTX == 1 && !LONG) ? LOC_KSTEPS : 2;   // as far as the instance's registers allow without spilling
                                                                     // (4 and 8 measured slower in the two-chunk instance)
   // The two-chunk instance does the work in two passes (the wave's even and odd tiles), which a frame places in two
   // different shadows; the one-chunk instance does everything in pass 0 (splitting it measured 0.1 us slower there).
@@ -472,7 +479,7 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
       }
       return acc;
     };
-    if (NCTX == 1) {
+    if (NCTX == 1 && !LONG) {
       // every position's processed memory is in LDS (the one-chunk instance runs inputs of up to LQ_PM_POS positions)
       if (pass != 0) return;
       _Pragma("unroll 1") for (int s0 = q_lo + wave * 16; s0 < q_hi; s0 += NW * 16) {
@@ -480,7 +487,7 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int d = 4 * kq + r;
-          lds[LQ_U + d * TACO_MAX_TIN + s0 + col] = acc[r] + lds[LQ_PM + d * LQ_PM_POS + s0 + col];
+          lds[LQ_U + d * TACO_Q_POS + (s0 - q_lo) + col] = acc[r] + lds[LQ_PM + d * LQ_PM_POS + s0 + col];
         }
       }
     } else {
@@ -495,7 +502,7 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
           if (s < len && 4 * kq + r < q_cnt) pmv[r] = a.pm[(size_t)s * A + q_base + 4 * kq + r];
         const taco_f32x4 acc = tile_products(s0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) lds[LQ_U + (4 * kq + r) * TACO_MAX_TIN + s] = acc[r] + pmv[r];
+        for (int r = 0; r < 4; ++r) lds[LQ_U + (4 * kq + r) * TACO_Q_POS + (s - q_lo)] = acc[r] + pmv[r];
       }
     }
   };
@@ -627,8 +634,8 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
       vv[1] = lds[LQ_V + wave * 2 + 1];
       TACO_QSTAMP(1);
       _Pragma("unroll 2") for (int s = q_lo + lane; s < q_hi; s += 64) {
-        const float e0 = vv[0] * taco_tanh(qv[0] + lds[LQ_U + (wave * 2 + 0) * TACO_MAX_TIN + s]);
-        const float e1 = vv[1] * taco_tanh(qv[1] + lds[LQ_U + (wave * 2 + 1) * TACO_MAX_TIN + s]);
+        const float e0 = vv[0] * taco_tanh(qv[0] + lds[LQ_U + (wave * 2 + 0) * TACO_Q_POS + (s - q_lo)]);
+        const float e1 = vv[1] * taco_tanh(qv[1] + lds[LQ_U + (wave * 2 + 1) * TACO_Q_POS + (s - q_lo)]);
         lds[LQ_PE8 + wave * TACO_MAX_TIN + s] = e0 + e1;
       }
       TACO_QSTAMP(2);
@@ -662,34 +669,50 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
     // the unnormalised weights meet in LDS; then every wave picks the weights up in the layout of its
     // folded-context columns (lane l: positions 4l..4l+3 of each chunk) and normalises them in registers.
     float4 wgt[NCTX];
-    float w_own;
+    float w_own[NPOS];
+    float inv_sum;
     {
-      float e = 0.0f;
-      if (tid < len)
-        for (int gq = 0; gq < n_q_wg; ++gq) e += lds[L_PE + gq * len4 + tid];
+      float e[NPOS], x[NPOS];
+#pragma unroll
+      for (int q = 0; q < NPOS; ++q) {
+        const int sq = tid + q * NT;
+        e[q] = 0.0f;
+        if (sq < len)
+          for (int gq = 0; gq < n_q_wg; ++gq) e[q] += lds[L_PE + gq * len4 + sq];
+      }
       float mx = 0.0f;
       if (a.shift_energies) {
-        const float m = taco_wave_max(tid < len ? e : -INFINITY);
+        float m = tid < len ? e[0] : -INFINITY;
+#pragma unroll
+        for (int q = 1; q < NPOS; ++q) m = fmaxf(m, tid + q * NT < len ? e[q] : -INFINITY);
+        m = taco_wave_max(m);
         if (lane == 0) lds[L_RED + 8 + wave] = m;
         taco_lds_barrier();
         const float4 m0 = *reinterpret_cast<const float4*>(lds + L_RED + 8);
         const float4 m1 = *reinterpret_cast<const float4*>(lds + L_RED + 12);
         mx = fmaxf(fmaxf(fmaxf(m0.x, m0.y), fmaxf(m0.z, m0.w)), fmaxf(fmaxf(m1.x, m1.y), fmaxf(m1.z, m1.w)));
       }
-      const float x = tid < len ? taco_exp(e - mx) : 0.0f;
-      lds[L_X + tid] = x;
-      const float part = taco_wave_sum(x);
+      float xs = 0.0f;
+#pragma unroll
+      for (int q = 0; q < NPOS; ++q) {
+        x[q] = tid + q * NT < len ? taco_exp(e[q] - mx) : 0.0f;
+        lds[L_X + tid + q * NT] = x[q];
+        xs += x[q];
+      }
+      const float part = taco_wave_sum(xs);
       if (lane == 0) lds[L_RED + wave] = part;
       taco_lds_barrier();
       const float4 s0 = *reinterpret_cast<const float4*>(lds + L_RED);
       const float4 s1 = *reinterpret_cast<const float4*>(lds + L_RED + 4);
       const float inv = 1.0f / (((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w)));
+      inv_sum = inv;
 #pragma unroll
       for (int c = 0; c < NCTX; ++c) {
         const float4 xv = *reinterpret_cast<const float4*>(lds + L_X + c * TACO_CHUNK + lane * 4);
         wgt[c] = make_float4(xv.x * inv, xv.y * inv, xv.z * inv, xv.w * inv);
       }
-      w_own = x * inv;
+#pragma unroll
+      for (int q = 0; q < NPOS; ++q) w_own[q] = x[q] * inv;
     }
 
     // ============ S7: decoder LSTM; the context enters as G * w, no hand-off ============
@@ -698,6 +721,20 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
     if (act_d) {
 #pragma unroll
       for (int c = 0; c < NCTX; ++c) dot_reg(wd[0][TACO_NA + c], wd[1][TACO_NA + c], wgt[c], acc_d);
+      if (LONG) {
+        // the folded context columns of the positions beyond the registers': from global memory, against the
+        // unnormalised weights every thread has just left in LDS
+        float g0 = 0.0f, g1 = 0.0f;
+        const float* r0 = G_dec + (size_t)(gate0 * Rd + gu_d) * a.T_in;
+        const float* r1 = G_dec + (size_t)((gate0 + 1) * Rd + gu_d) * a.T_in;
+        for (int sp = ONCHIP + lane; sp < len; sp += 64) {
+          const float xv = lds[L_X + sp];
+          g0 = fmaf(r0[sp], xv, g0);
+          g1 = fmaf(r1[sp], xv, g1);
+        }
+        acc_d[0] = fmaf(g0, inv_sum, acc_d[0]);
+        acc_d[1] = fmaf(g1, inv_sum, acc_d[1]);
+      }
       float s0, s1;
       taco_wave_sum2(acc_d[0], acc_d[1], s0, s1);
       if (lane == 0) {
@@ -715,18 +752,28 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
     // Behind the publish: each thread leaves its position's weight in LDS for the projection rows, the location
     // term and the next frame's attention-LSTM partial sums, accumulates it, and the last workgroup writes the
     // alignment row.
-    lds[L_AW + HALO + tid] = w_own;
-    if (tid < len) {
-      lds[L_CUM + HALO + tid] += w_own;
-      if (j == n_wg - 1 && a.align) a.align[(size_t)t * a.T_in + tid] = w_own;
+#pragma unroll
+    for (int q = 0; q < NPOS; ++q) {
+      const int sq = tid + q * NT;
+      lds[L_AW + HALO + sq] = w_own[q];
+      if (sq < len) {
+        lds[L_CUM + HALO + sq] += w_own[q];
+        if (j == n_wg - 1 && a.align) a.align[(size_t)t * a.T_in + sq] = w_own[q];
+      }
     }
     if (a.frame_clock && j == n_wg - 1 && tid == 0 && t < a.frame_clock_cap) a.frame_clock[t] = wall_clock64();
     taco_lds_barrier();
     TACO_STAMP(8);
     // meanwhile: folded-context half of my projection rows (M group)
     float acc_p = 0.0f;
-    if (own_m) acc_p = row_partial<NCTX>(my_proj + TACO_ND * TACO_CHUNK, aw, lane);
-    if (own_p && !forced) acc_p = row_partial<NCTX>(my_wf + TACO_ND * TACO_CHUNK, aw, lane) + (lane == 0 ? lds[LP_BIAS + wave] : 0.0f);   // ... of my folded layer-1 row, with its bias
+    constexpr int NROW = ROW_ONCHIP / TACO_CHUNK;
+    if (own_m) acc_p = row_partial<NROW>(my_proj + TACO_ND * TACO_CHUNK, aw, lane);
+    if (own_p && !forced) acc_p = row_partial<NROW>(my_wf + TACO_ND * TACO_CHUNK, aw, lane) + (lane == 0 ? lds[LP_BIAS + wave] : 0.0f);   // ... of my folded layer-1 row, with its bias
+    if (LONG && (own_m || (own_p && !forced))) {
+      // ... and the positions beyond the LDS rows', from global memory
+      const float* grow = own_m ? G_proj + (size_t)m_row * a.T_in : G_proj + (size_t)(NMEL + 1 + p_row) * a.T_in;
+      for (int sp = ROW_ONCHIP + lane; sp < len; sp += 64) acc_p = fmaf(grow[sp], aw[sp], acc_p);
+    }
     TACO_STAMP(9);
 
     // ============ S8: mel / stop-token projection rows (M group), next frame's prenet layer 1 (P group) ============
@@ -770,6 +817,18 @@ __global__ __launch_bounds__(TACO_DEC_THREADS) void taco_decoder_kernel(const De
     if (act_a) {
       dot_chunks<1>(wa[0] + TACO_NP, wa[1] + TACO_NP, aw, lane, acc_a);
       if (NCTX > 1) dot_chunks<1>(wa[0] + TACO_NP + NCTX - 1, wa[1] + TACO_NP + NCTX - 1, aw + TACO_CHUNK, lane, acc_a);
+      if (LONG) {
+        const float* r0 = G_att + (size_t)(gate0 * Ra + gu_a) * a.T_in;
+        const float* r1 = G_att + (size_t)((gate0 + 1) * Ra + gu_a) * a.T_in;
+        float g0 = 0.0f, g1 = 0.0f;
+        for (int sp = ONCHIP + lane; sp < len; sp += 64) {
+          const float xv = aw[sp];
+          g0 = fmaf(r0[sp], xv, g0);
+          g1 = fmaf(r1[sp], xv, g1);
+        }
+        acc_a[0] += g0;
+        acc_a[1] += g1;
+      }
       dot_chunks<TACO_NA>(wa[0] + TACO_NP + NCTX, wa[1] + TACO_NP + NCTX, lds + L_XAH, lane, acc_a);
     }
   }
@@ -886,6 +945,8 @@ int taco_launch_decoder(taco_handle h, const float* memory, const float* pm, int
   const bool one_chunk = own_len <= TACO_CHUNK;
   auto kern = std_geom ? (one_chunk ? taco_decoder_kernel<true, 1> : taco_decoder_kernel<true, 2>)
                        : (one_chunk ? taco_decoder_kernel<false, 1> : taco_decoder_kernel<false, 2>);
+  // beyond the positions whose folded context columns fit on chip: the instance that reads the rest from global memory
+  if (own_len > TACO_FOLD_TIN) kern = std_geom ? taco_decoder_kernel<true, 1, true> : taco_decoder_kernel<false, 1, true>;
   hipLaunchKernelGGL(kern, dim3(n_wg), dim3(NT), taco_decoder_lds_bytes(), s, a);
   TACO_HIP(hipGetLastError());
   return TACO_OK;
@@ -1003,8 +1064,9 @@ void taco_decoder_fill_layout(taco_dec_layout* lay, int n_wg) { fill_layout(*lay
 
 int taco_decoder_prepare(taco_handle h) {
   // the kernel needs more than the default 64 KiB of dynamic LDS
-  const void* kernels[4] = {reinterpret_cast<const void*>(taco_decoder_kernel<true, 1>), reinterpret_cast<const void*>(taco_decoder_kernel<true, 2>),
-                            reinterpret_cast<const void*>(taco_decoder_kernel<false, 1>), reinterpret_cast<const void*>(taco_decoder_kernel<false, 2>)};
+  const void* kernels[6] = {reinterpret_cast<const void*>(taco_decoder_kernel<true, 1>), reinterpret_cast<const void*>(taco_decoder_kernel<true, 2>),
+                            reinterpret_cast<const void*>(taco_decoder_kernel<false, 1>), reinterpret_cast<const void*>(taco_decoder_kernel<false, 2>),
+                            reinterpret_cast<const void*>(taco_decoder_kernel<true, 1, true>), reinterpret_cast<const void*>(taco_decoder_kernel<false, 1, true>)};
   for (const void* k : kernels) {
     // the kernel needs more than the default 64 KiB of dynamic LDS; one workgroup must fit on a CU
     TACO_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)taco_decoder_lds_bytes()));

@@ -30,7 +30,9 @@ constexpr int TACO_MAX_A = 128;
 constexpr int TACO_MAX_F = 32;
 constexpr int TACO_MAX_K = 31;
 constexpr int TACO_MAX_MEL = 80;            // prenet layer 1 is replicated in every workgroup's LDS
-constexpr int TACO_MAX_TIN = 512;           // symbols per utterance
+constexpr int TACO_MAX_TIN = 1024;          // symbols per utterance (the batch-1 decoder's capacity)
+constexpr int TACO_FOLD_TIN = 512;          // positions whose folded context weights a workgroup keeps on chip (registers / LDS);
+                                            // longer utterances read the rest from global memory every frame
 constexpr int TACO_DEC_THREADS = 512;       // 8 waves: two LSTM gate rows per wave
 constexpr int TACO_UNITS_PER_WG = 4;        // 4 hidden units x 4 gates = 16 rows per LSTM per workgroup
 // Producer groups of the decoder's short vectors (see taco_decoder.hip)

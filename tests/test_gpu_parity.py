@@ -309,13 +309,14 @@ def test_no_step_limit_stops_on_the_stop_token():
 
 def test_long_input_full_size_model(gate_table):
   """Default-geometry model over the range of input lengths - a single symbol, lengths around the 256-position
-  boundary of the folded-context chunks, the 512-position capacity (several position tiles per wave in the
-  location term) - against the oracle."""
+  boundary of the folded-context chunks, the 512 positions whose folded context columns stay on chip, and beyond
+  them up to the 1024-position capacity (the instance that reads the other positions' columns from global memory;
+  the reference itself has no bound on the input length, src/tacotron/model.py:529-568) - against the oracle."""
   gate = gate_table["ljs"]
   om = oracle_model("ljs", gate)
   gm = gpu_model("ljs", gate)
   ck = scenario_checkpoint("ljs", gate)
-  for T_in, max_steps in ((1, 6), (64, 40), (129, 12), (256, 8), (257, 8), (384, 8), (512, 5)):
+  for T_in, max_steps in ((1, 6), (64, 40), (129, 12), (256, 8), (257, 8), (384, 8), (512, 5), (513, 6), (768, 5), (1024, 5)):
     ids = scenarios.random_ids(ck, [T_in], seed=900 + T_in)
     masks = prenet_keep_masks(3, max_steps, om.dims.P)
     mem_o, pm_o = om.encode(chans(ids), ids["speakers"], None)
@@ -327,7 +328,7 @@ def test_long_input_full_size_model(gate_table):
     np.testing.assert_allclose(gate_g[0].cpu().numpy(), gate_o[0], atol=FREE_TOL, rtol=0)
     np.testing.assert_allclose(align[0].cpu().numpy(), align_o[0], atol=FREE_TOL, rtol=0)
   with pytest.raises(Exception):
-    ids = scenarios.random_ids(ck, [513], seed=1)
+    ids = scenarios.random_ids(ck, [1025], seed=1)
     mem, pm = gm.encode([dev(c) for c in chans(ids)], dev(ids["speakers"]), None)
     gm.decode(mem, pm, None, prenet_keep_masks(3, 2, om.dims.P), 2)
 
@@ -336,7 +337,7 @@ def test_padded_batch_across_the_chunk_boundary(gate_table):
   """A padded batch whose longest line has more than 256 symbols (so every utterance runs the instance with two
   folded-context chunks) while others are short or exactly 256: each utterance must equal its own unpadded
   oracle run, and everything past its length and its frames must be zero."""
-  for name, lens, max_steps in (("tiny", [300, 40, 256, 7], 10), ("ljs", [260, 33], 6)):
+  for name, lens, max_steps in (("tiny", [300, 40, 256, 7], 10), ("ljs", [260, 33], 6), ("tiny", [700, 513, 90], 9)):
     gate = gate_table[name]
     om = oracle_model(name, gate)
     gm = gpu_model(name, gate)

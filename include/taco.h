@@ -200,8 +200,11 @@ int taco_postnet_noalloc(taco_handle h, const float* mel, const int32_t* n_frame
                          float* out, void* stream);
 
 /* Device-side duration of the most recent taco_decode on this handle, measured with HIP events
- * recorded on the caller's stream around the persistent launch: writes microseconds in total and
- * the number of frames the longest utterance produced.  Synchronises on the stop event. */
+ * recorded on the caller's stream around the call's persistent launches: writes microseconds in total and
+ * the largest frame count among those launches - for a batch-1 launch the frames its utterance produced, for a
+ * lockstep launch its number of lockstep frames (every one advances up to sixteen utterances; refills and the up
+ * to three frames a slot waits before a start included), NOT the frames of the longest utterance.  Synchronises on
+ * the stop event. */
 int taco_last_decode_timing(taco_handle h, double* total_us, int32_t* frames);
 
 /* Per-frame step latency (measurement helper, no counterpart in the reference): from now on the decoder

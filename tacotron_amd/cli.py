@@ -371,10 +371,20 @@ def synthesize_ns(ns: argparse.Namespace, synthesizer_factory: Optional[Callable
   # other's first outputs as "already synthesized" and disagree about the shards.
   if n_ranks > 1:
     import torch.distributed as dist
-    box = [plan_outputs(paragraphs, lines_to_infer, output_directory, ns.paragraph_directories, ns.prepend, ns.append,
-                        ns.overwrite, ns.include_stats, log) if rank == 0 else None]
+    box = [None]
+    if rank == 0:
+      # whatever rank 0 runs into here (an unreadable output folder, say) travels to the others in place of the plan:
+      # they would otherwise wait in the broadcast until the process group's timeout
+      try:
+        box = [("plan", plan_outputs(paragraphs, lines_to_infer, output_directory, ns.paragraph_directories, ns.prepend,
+                                     ns.append, ns.overwrite, ns.include_stats, log))]
+      except Exception as ex:  # pylint: disable=broad-except
+        box = [("error", f"{type(ex).__name__}: {ex}")]
     dist.broadcast_object_list(box, src=0, group=group)
-    plan = box[0]
+    kind, plan = box[0]
+    if kind == "error":
+      log.error(f"Planning the output files failed on rank 0: {plan}")
+      return False
   else:
     plan = plan_outputs(paragraphs, lines_to_infer, output_directory, ns.paragraph_directories, ns.prepend, ns.append,
                         ns.overwrite, ns.include_stats, log)

@@ -843,8 +843,10 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
       bt_issue<NL_P>(rs, par + w_lane_p, v);
       bt_check<NL_P, 0, NL_P>(rs, par + w_lane_p, tag, v, wctx, 0x400u);
       nap_p = bt_nap_adjust(nap_p, wctx.spun);
-      if (fresh) {           // the first frame of an utterance is fed the all-zero frame: its prenet output is zero
-        if ((fresh >> utt) & 1u) {
+      if (fresh || t == 0) { // the first frame of an utterance is fed the all-zero frame: its prenet output is zero (exact
+                             // zeros also for the utterances that start with the launch, whose published words are
+                             // zeros with tag bits: both kinds of start then take the same arithmetic)
+        if (t == 0 || ((fresh >> utt) & 1u)) {
 #pragma unroll
           for (int i = 0; i < NL_P; ++i) v[i] = u32x4{0u, 0u, 0u, 0u};
         }

@@ -27,6 +27,10 @@ def main():
         time.sleep(3.0)
       return oracle_synthesizer(*args, **kwargs)
 
+    if os.environ.get("SHARD_WORKER_FAIL_PLAN") and int(os.environ.get("RANK", "0")) == 0:
+      def broken_plan(*args, **kwargs):   # rank 0 cannot plan (an unreadable output folder, say)
+        raise PermissionError("output folder cannot be listed")
+      cli.plan_outputs = broken_plan
     ok = ns.handler(ns, synthesizer_factory=factory)
     rank, n = sharding.world()
     print(f"rank {rank}/{n} ok={ok}", flush=True)

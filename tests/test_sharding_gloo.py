@@ -93,6 +93,19 @@ def test_a_slow_rank_plans_the_same_lines_without_overwrite(tmp_path):
     np.testing.assert_array_equal(np.load(tmp_path / "one" / n), np.load(tmp_path / "two" / n))
 
 
+def test_a_failed_plan_on_rank_0_ends_every_rank(tmp_path):
+  """Only rank 0 plans the output files; when that fails, the other ranks (waiting for the plan) must get the error
+  and end with a failure status instead of waiting for the process group's timeout."""
+  text = tmp_path / "in.txt"
+  text.write_text("s1|s2|s3\ns4|s5", encoding="UTF-8")
+  res = _launch(2, ["synthesize", TINY_CKPT, str(text), "--sep", "|", "--custom-seed", "5", "--max-decoder-steps", "6",
+                    "-out", str(tmp_path / "out")], timeout=120, extra_env={"SHARD_WORKER_FAIL_PLAN": "1"})
+  assert res.returncode != 0
+  assert "rank 0/2 ok=False" in res.stdout and "rank 1/2 ok=False" in res.stdout, res.stdout + res.stderr
+  assert "output folder cannot be listed" in res.stdout + res.stderr
+  assert not (tmp_path / "out").exists()
+
+
 def test_a_failing_rank_is_reported_on_every_rank_without_a_hang():
   res = _launch(2, ["fail"], timeout=120)
   assert res.returncode == 0, res.stdout + res.stderr

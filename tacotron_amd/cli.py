@@ -187,26 +187,60 @@ def synthesize_plan(synth, plan: Sequence[PlannedLine], speaker: Optional[str], 
         out[i] = future.result()
 
     groups = list(sharding.batches(indices, batch_size))
+    # The stages below are threads of one interpreter.  A thread that comes back from a library call (this one, after
+    # every GPU call) waits for the interpreter lock until the thread holding it is asked to let go, by default after
+    # 5 ms - several times per batch, with the GPU idle.  A shorter interval makes those hand-overs prompt.
+    switch_interval = sys.getswitchinterval()
+    if batch_size > 1:
+      sys.setswitchinterval(min(switch_interval, 2e-4))
+    try:
+      return staged(groups, pending, out, settle)
+    finally:
+      sys.setswitchinterval(switch_interval)
+
+  def staged(groups, pending, out, settle) -> Dict[int, Dict[str, object]]:
     with concurrent.futures.ThreadPoolExecutor(max_workers=WRITERS, thread_name_prefix="taco-write") as writer, \
-         concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="taco-prep") as prep:
-      # In batch mode the next batch's symbols are mapped to ids on a second thread while the GPU decodes the
-      # current one (the library call releases the interpreter lock for as long as the decoder runs).
+         concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="taco-prep") as prep, \
+         concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="taco-finish") as finisher:
+      # Batch mode is a pipeline of three stages.  This thread keeps the GPU busy: it launches a batch (encoder, decoder,
+      # postnet, copies to the host enqueued) and goes straight on to the next one.  A second thread has mapped that
+      # batch's symbols to ids meanwhile, and a third waits for a launched batch's copies, cuts it into lines, has the
+      # writer threads store them and gives the batch's staging buffers back.  The library call releases the
+      # interpreter lock for as long as the decoder runs, so the other stages run beside it.
+      pipelined = batch_size > 1 and hasattr(synth, "launch_batch") and hasattr(synth, "prepare_batch")
       ahead = None
-      if batch_size > 1 and groups and hasattr(synth, "prepare_batch"):
+      if pipelined and groups:
         ahead = prep.submit(synth.prepare_batch, [plan[i].symbols for i in groups[0]], speaker)
+      finishing: "collections.deque" = collections.deque()
+
+      def finish(group_idx: List[int], launched) -> Dict[int, Dict[str, object]]:
+        results = synth.finish_batch(launched)
+        written = [writer.submit(_write_line, plan[i], res, include_stats) for i, res in zip(group_idx, results)]
+        records = {i: f.result() for i, f in zip(group_idx, written)}
+        launched.release()                   # the lines' arrays were views into the batch's staging buffers
+        return records
+
       for g, group_idx in enumerate(groups):
+        if pipelined:
+          prepared = ahead.result()
+          ahead = prep.submit(synth.prepare_batch, [plan[i].symbols for i in groups[g + 1]], speaker) if g + 1 < len(groups) else None
+          launched = synth.launch_batch([plan[i].symbols for i in group_idx], speaker=speaker, max_decoder_steps=max_decoder_steps,
+                                        seed=seed, include_stats=include_stats, prepared=prepared)
+          finishing.append(finisher.submit(finish, group_idx, launched))
+          while len(finishing) > 2:          # (a batch's staging set is free again when its lines have been written)
+            out.update(finishing.popleft().result())
+          continue
         if batch_size == 1:
           results = [synth.infer(symbols=plan[group_idx[0]].symbols, speaker=speaker, include_stats=include_stats,
                                  max_decoder_steps=max_decoder_steps, seed=seed)]
         else:
-          prepared = ahead.result() if ahead is not None else None
-          if ahead is not None:
-            ahead = prep.submit(synth.prepare_batch, [plan[i].symbols for i in groups[g + 1]], speaker) if g + 1 < len(groups) else None
           results = synth.infer_batch([plan[i].symbols for i in group_idx], speaker=speaker, max_decoder_steps=max_decoder_steps,
-                                      seed=seed, include_stats=include_stats, **({} if prepared is None else {"prepared": prepared}))
+                                      seed=seed, include_stats=include_stats)
         for i, res in zip(group_idx, results):
           pending.append((i, writer.submit(_write_line, plan[i], res, include_stats)))
         settle(max(WRITE_BEHIND, batch_size))
+      while finishing:
+        out.update(finishing.popleft().result())
       settle(0)
     return out
 

@@ -10,6 +10,7 @@ from __future__ import annotations
 import logging
 import os
 import random
+import queue
 import time
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Set, Tuple, Union
@@ -72,6 +73,9 @@ def spectrogram_duration_s(n_frames: int, n_fft: int, hop_length: int, sr: int =
   return float(n_samples) / sr
 
 
+STAGING_SETS = 3        # batches whose host arrays may be alive at once (one being written, one being copied, one free)
+
+
 @dataclass
 class _Prepared:
   ids: Dict[str, Optional[List[int]]]
@@ -115,7 +119,6 @@ class Synthesizer:
     self.model = model.to(self.device).eval()
     if precision != "fp32":
       self.model.set_precision(precision)
-    self._staging: Dict[int, torch.Tensor] = {}
 
   def get_sampling_rate(self) -> int:
     return self.hparams.sampling_rate
@@ -124,19 +127,32 @@ class Synthesizer:
     if self.device.type == "cuda":
       torch.cuda.synchronize(self.device)
 
-  def _to_host(self, t: torch.Tensor, which: int) -> np.ndarray:
-    """Copies a device tensor into a page-locked staging buffer kept per output array (a pageable destination makes
-    the runtime bounce the copy through its own small pinned buffers at a fraction of the link's rate) and returns
-    the buffer as an array: valid until the next call with the same ``which``."""
+  def _staging_pool(self) -> "queue.Queue":
+    """Page-locked staging sets for the device-to-host copies of batches: a batch keeps its set until its arrays have
+    been consumed (``finish_batch`` ... ``release``), so that the next batch can be decoded meanwhile."""
+    pool = getattr(self, "_staging_sets", None)
+    if pool is None:
+      pool = queue.Queue()
+      for _ in range(STAGING_SETS):
+        pool.put({})
+      self._staging_sets = pool
+    return pool
+
+  def _to_host(self, t: torch.Tensor, which: int, staging: Dict[int, torch.Tensor], wait: bool = True) -> np.ndarray:
+    """Copies a device tensor into a page-locked staging buffer of the set ``staging`` (one buffer per output array; a
+    pageable destination makes the runtime bounce the copy through its own small pinned buffers at a fraction of the
+    link's rate) and returns the buffer as an array: valid until the set is used again.  ``wait=False`` only enqueues
+    the copy on the current stream."""
     if t.device.type != "cuda":
       return t.contiguous().numpy()
-    have = self._staging.get(which)
+    have = staging.get(which)
     if have is None or have.numel() < t.numel():
       have = torch.empty(max(t.numel(), 1), dtype=t.dtype, pin_memory=True)
-      self._staging[which] = have
+      staging[which] = have
     dst = have[:t.numel()].view(t.shape)
     dst.copy_(t, non_blocking=True)
-    self._sync()
+    if wait:
+      self._sync()
     return dst.numpy()
 
   # ---- host logic: symbols -> ids, dropping positions no mapping knows ---------------------------
@@ -238,6 +254,23 @@ class Synthesizer:
     ``prepared``: what ``prepare_batch(lines, speaker)`` returned, if the caller ran it ahead of time."""
     if len(lines) == 0:
       return []
+    pending = self.launch_batch(lines, speaker, max_decoder_steps, seed, include_stats, keep_on_device, prepared)
+    results = self.finish_batch(pending)
+    if not keep_on_device:
+      for res in results:                      # the staging set goes back: the arrays must own their memory
+        res.mel_outputs_postnet = res.mel_outputs_postnet.copy()
+        if include_stats:
+          res.mel_outputs, res.gate_outputs, res.alignments = res.mel_outputs.copy(), res.gate_outputs.copy(), res.alignments.copy()
+    pending.release()
+    return results
+
+  def launch_batch(self, lines: Sequence[Sequence[str]], speaker: Optional[str], max_decoder_steps: int = 3000,
+                   seed: int = 0, include_stats: bool = False, keep_on_device: bool = False,
+                   prepared: Optional[List[_Prepared]] = None) -> "_PendingBatch":
+    """The device half of ``infer_batch``: encoder, decoder (the call returns when the decoder has finished), postnet
+    and the copies to the host are enqueued, the copies are NOT waited for.  ``finish_batch`` waits for them and cuts
+    the batch into per-line results - a caller with many batches runs it on another thread while this thread launches
+    the next batch, so the GPU does not idle while the host slices and writes."""
     preps = prepared if prepared is not None else self.prepare_batch(lines, speaker)
     lens = [len(p.ids["symbols"]) for p in preps]
     T = max(lens)
@@ -255,33 +288,68 @@ class Synthesizer:
     if self.hparams.use_speaker_embedding:
       speakers = torch.full((len(preps), T), preps[0].speaker_id, dtype=torch.int64, device=self.device)
     lens_t = torch.tensor(lens, dtype=torch.int32, device=self.device)
-    self._sync()
     start = time.perf_counter()
     mel, post, gate, align, n_frames, reached = self.model.inference_batch(
       padded("symbols"), padded("stresses"), padded("tones"), padded("durations"), speakers, lens_t,
       max_decoder_steps, want_align=include_stats)
-    self._sync()
-    seconds = (time.perf_counter() - start) / len(preps)
+    # (the decoder has finished - its call waits for it -, so the frame counts are final; the postnet is still running)
     n_frames = n_frames.cpu().tolist()
     reached = reached.cpu().tolist()
-    if not keep_on_device:
-      # one copy per array for the whole batch (up to its longest utterance), sliced per line on the host
-      n_max = max(n_frames)
-      post = self._to_host(post[:, :, :n_max], 0)
-      if include_stats:
-        mel, gate, align = (self._to_host(mel[:, :, :n_max], 1), self._to_host(gate[:, :n_max], 2),
-                            self._to_host(align[:, :n_max], 3))
+    pending = _PendingBatch(self, preps, lens, n_frames, reached, include_stats, keep_on_device, start)
+    if keep_on_device:
+      pending.arrays = (post, mel, gate, align)
+      return pending
+    # one copy per array for the whole batch (up to its longest utterance), sliced per line on the host
+    n_max = max(n_frames)
+    staging = self._staging_pool().get()
+    pending.staging = staging
+    post_h = self._to_host(post[:, :, :n_max], 0, staging, wait=False)
+    mel_h = gate_h = align_h = None
+    if include_stats:
+      mel_h, gate_h, align_h = (self._to_host(mel[:, :, :n_max], 1, staging, wait=False),
+                                self._to_host(gate[:, :n_max], 2, staging, wait=False),
+                                self._to_host(align[:, :n_max], 3, staging, wait=False))
+    pending.arrays = (post_h, mel_h, gate_h, align_h)
+    if self.device.type == "cuda":
+      pending.copied = torch.cuda.Event()
+      pending.copied.record(torch.cuda.current_stream(self.device))
+    pending.keep = (post, mel, gate, align)      # the device tensors live until the copies have been waited for
+    return pending
 
-    def own(a):
-      return a if keep_on_device else a.copy()     # the staging buffers are reused by the next batch
-
+  def finish_batch(self, pending: "_PendingBatch") -> List[InferenceResult]:
+    """Waits for a launched batch's copies and returns its per-line results.  Unless the batch stayed on the device,
+    the arrays are views into the batch's page-locked staging set: valid until ``pending.release()``."""
+    if pending.copied is not None:
+      pending.copied.synchronize()
+    pending.keep = None
+    seconds = (time.perf_counter() - pending.start) / len(pending.preps)
+    post, mel, gate, align = pending.arrays
+    on_device = pending.keep_on_device
     out = []
-    for b, p in enumerate(preps):
-      n = n_frames[b]
-      res = self._result(p, own(post[b, :, :n]), bool(reached[b]), seconds)
-      if include_stats:
-        res.mel_outputs = own(mel[b, :, :n])
-        res.gate_outputs = own(gate[b, :n, None] if not keep_on_device else gate[b, :n].unsqueeze(-1))
-        res.alignments = own(align[b, :n, :lens[b]])
+    for b, p in enumerate(pending.preps):
+      n = pending.n_frames[b]
+      res = self._result(p, post[b, :, :n], bool(pending.reached[b]), seconds)
+      if pending.include_stats:
+        res.mel_outputs = mel[b, :, :n]
+        res.gate_outputs = gate[b, :n, None] if not on_device else gate[b, :n].unsqueeze(-1)
+        res.alignments = align[b, :n, :pending.lens[b]]
       out.append(res)
     return out
+
+
+class _PendingBatch:
+  """A batch between ``launch_batch`` and ``finish_batch`` / ``release``."""
+
+  def __init__(self, synth, preps, lens, n_frames, reached, include_stats, keep_on_device, start):
+    self.synth, self.preps, self.lens, self.n_frames, self.reached = synth, preps, lens, n_frames, reached
+    self.include_stats, self.keep_on_device, self.start = include_stats, keep_on_device, start
+    self.staging = None
+    self.arrays = None
+    self.copied = None
+    self.keep = None
+
+  def release(self) -> None:
+    """Gives the batch's staging set back (its result arrays must not be used afterwards)."""
+    if self.staging is not None:
+      self.synth._staging_pool().put(self.staging)
+      self.staging = None

@@ -170,6 +170,27 @@ int taco_decode(taco_handle h, const float* memory, const float* processed_memor
                 float gate_threshold, const float* forced_mel, float* mel, float* gate, float* align,
                 int32_t* n_frames, uint8_t* reached_max, void* stream);
 
+/* taco_decode that may stop before every utterance has finished, and take the unfinished ones up again in a later call
+ * (no counterpart in the reference, whose loop decodes one utterance at a time: src/tacotron/model.py:529-568).  A call
+ * of many utterances ends with a tail in which most of the sixteen slots are empty; with `leave_unfinished` the lockstep
+ * launch ends as soon as a slot has no successor instead, and the utterances still running keep their state inside the
+ * handle.  For each of them n_frames[b] = the frames it has so far, reached_max[b] = 2 and slot_out[b] = its slot; the
+ * frames are in mel / gate / align as far as they go.  The caller puts those utterances into its next call - the same
+ * memory / processed_memory rows again, at any index - with resume_slot[b] = that slot: they go on from their next
+ * frame, writing columns n_frames[b].. of the NEW call's outputs (the caller copies the earlier columns over), bit for
+ * bit as if they had never been interrupted.  The handle keeps ONE such state: every left utterance must be resumed by
+ * the next lockstep call on the handle (or abandoned by not naming its slot), with the same masks and limits.
+ *   resume_slot       device [B] int32 or NULL: slot to continue from, -1 = the utterance starts anew
+ *   leave_unfinished  0 = run every utterance to its end (what taco_decode does)
+ *   slot_out          device [B] int32 (required unless both of the above are NULL / 0): -1, or the slot b was left in
+ * Utterances too long for the lockstep decoder (over 224 symbols) are decoded to their end by the batch-1 kernel as in
+ * taco_decode and cannot be resumed. */
+int taco_decode_resumable(taco_handle h, const float* memory, const float* processed_memory, const int32_t* lens,
+                          int32_t B, int32_t T_in, const uint8_t* masks, int32_t T_cap, int32_t max_steps,
+                          float gate_threshold, const float* forced_mel, float* mel, float* gate, float* align,
+                          int32_t* n_frames, uint8_t* reached_max, const int32_t* resume_slot,
+                          int32_t leave_unfinished, int32_t* slot_out, void* stream);
+
 /* Waits for the work enqueued on `stream` and reports what the encoder stage found: TACO_ERANGE when
  * an id passed to taco_encode was outside its embedding table / one-hot width (the reference's
  * nn.Embedding / F.one_hot raise for those: src/tacotron/model.py:585-609), TACO_ETIMEDOUT when the

@@ -19,7 +19,7 @@ CSRC_DIR = os.path.join(_PKG_DIR, "csrc")
 
 EXPORTED_SYMBOLS = (
   "taco_last_error", "taco_version", "taco_create", "taco_destroy", "taco_step_weight_bytes",
-  "taco_encode", "taco_encode_status", "taco_decode", "taco_postnet", "taco_postnet_noalloc", "taco_last_decode_timing",
+  "taco_encode", "taco_encode_status", "taco_decode", "taco_decode_resumable", "taco_postnet", "taco_postnet_noalloc", "taco_last_decode_timing",
   "taco_set_frame_clock", "taco_set_precision",
 )
 
@@ -62,6 +62,7 @@ def lib() -> C.CDLL:
   L.taco_encode.argtypes = [vp, C.POINTER(vp), vp, vp, i32, i32, vp, vp, vp]
   L.taco_encode_status.argtypes = [vp, vp]
   L.taco_decode.argtypes = [vp, vp, vp, vp, i32, i32, vp, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp]
+  L.taco_decode_resumable.argtypes = [vp, vp, vp, vp, i32, i32, vp, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp]
   L.taco_postnet.argtypes = [vp, vp, vp, i32, i32, vp, vp]
   L.taco_postnet_noalloc.argtypes = [vp, vp, vp, i32, i32, vp, vp]
   L.taco_last_decode_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i32)]

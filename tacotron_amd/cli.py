@@ -213,20 +213,28 @@ def synthesize_plan(synth, plan: Sequence[PlannedLine], speaker: Optional[str], 
         ahead = prep.submit(synth.prepare_batch, [plan[i].symbols for i in groups[0]], speaker)
       finishing: "collections.deque" = collections.deque()
 
-      def finish(group_idx: List[int], launched) -> Dict[int, Dict[str, object]]:
+      def finish(launched) -> Dict[int, Dict[str, object]]:
         results = synth.finish_batch(launched)
-        written = [writer.submit(_write_line, plan[i], res, include_stats) for i, res in zip(group_idx, results)]
-        records = {i: f.result() for i, f in zip(group_idx, written)}
+        written = [writer.submit(_write_line, plan[i], res, include_stats) for i, res in zip(launched.finished_tags, results)]
+        records = {i: f.result() for i, f in zip(launched.finished_tags, written)}
         launched.release()                   # the lines' arrays were views into the batch's staging buffers
         return records
+
+      # The decoder of batches keeps sixteen lines in flight; a batch that is decoded to its last line ends with most of
+      # those slots empty.  So every launch but the last stops as soon as a slot has no successor, and the lines still
+      # running head the next launch, where they go on from their next frame (same frames as if never interrupted).
+      resumable = pipelined and max_decoder_steps > 0 and getattr(getattr(synth, "model", None), "supports_resume", False)
+      carry: List[object] = []
 
       for g, group_idx in enumerate(groups):
         if pipelined:
           prepared = ahead.result()
           ahead = prep.submit(synth.prepare_batch, [plan[i].symbols for i in groups[g + 1]], speaker) if g + 1 < len(groups) else None
           launched = synth.launch_batch([plan[i].symbols for i in group_idx], speaker=speaker, max_decoder_steps=max_decoder_steps,
-                                        seed=seed, include_stats=include_stats, prepared=prepared)
-          finishing.append(finisher.submit(finish, group_idx, launched))
+                                        seed=seed, include_stats=include_stats, prepared=prepared, tags=group_idx, carry=carry,
+                                        leave_unfinished=resumable and g + 1 < len(groups))
+          carry = launched.unfinished
+          finishing.append(finisher.submit(finish, launched))
           while len(finishing) > 2:          # (a batch's staging set is free again when its lines have been written)
             out.update(finishing.popleft().result())
           continue

@@ -290,6 +290,8 @@ extern "C" int taco_create(const taco_dims* dims, const taco_weights* weights, i
     taco_decoder_batch_fill_layout(&h->bat_lay);
     TACO_CREATE_HIP(hipMalloc((void**)&h->bat_gran, taco_decoder_batch_handoff_bytes()));
     TACO_CREATE_HIP(hipMalloc((void**)&h->bat_wstream, taco_decoder_batch_wstream_floats() * sizeof(float)));
+    TACO_CREATE_HIP(hipMalloc((void**)&h->bat_carry, taco_decoder_batch_carry_floats() * sizeof(float)));
+    TACO_CREATE_HIP(hipMemset(h->bat_carry, 0, taco_decoder_batch_carry_floats() * sizeof(float)));
     rc = taco_decoder_batch_prepare(h);
     if (rc == TACO_OK) rc = taco_decoder_batch_pack(h);
     if (rc != TACO_OK) { taco_destroy(h); return rc; }
@@ -328,6 +330,7 @@ extern "C" int taco_destroy(taco_handle h) {
   if (h->dec_gran) (void)hipFree(h->dec_gran);
   if (h->bat_gran) (void)hipFree(h->bat_gran);
   if (h->bat_wstream) (void)hipFree(h->bat_wstream);
+  if (h->bat_carry) (void)hipFree(h->bat_carry);
   if (h->dec_ctl) (void)hipFree(h->dec_ctl);
   if (h->enc_ctl) (void)hipFree(h->enc_ctl);
   if (h->dec_ctl_host) (void)hipHostFree(h->dec_ctl_host);
@@ -414,8 +417,19 @@ extern "C" int taco_decode(taco_handle h, const float* memory, const float* proc
                            int32_t B, int32_t T_in, const uint8_t* masks, int32_t T_cap, int32_t max_steps,
                            float gate_threshold, const float* forced_mel, float* mel, float* gate, float* align,
                            int32_t* n_frames, uint8_t* reached_max, void* stream) {
+  return taco_decode_resumable(h, memory, processed_memory, lens, B, T_in, masks, T_cap, max_steps, gate_threshold, forced_mel,
+                               mel, gate, align, n_frames, reached_max, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int taco_decode_resumable(taco_handle h, const float* memory, const float* processed_memory, const int32_t* lens,
+                                     int32_t B, int32_t T_in, const uint8_t* masks, int32_t T_cap, int32_t max_steps,
+                                     float gate_threshold, const float* forced_mel, float* mel, float* gate, float* align,
+                                     int32_t* n_frames, uint8_t* reached_max, const int32_t* resume_slot,
+                                     int32_t leave_unfinished, int32_t* slot_out, void* stream) {
   if (!h || !memory || !processed_memory || !masks || !mel || !gate || !n_frames || !reached_max)
     TACO_FAIL(TACO_EINVAL, "taco_decode: NULL argument");
+  if ((resume_slot || leave_unfinished) && !slot_out) TACO_FAIL(TACO_EINVAL, "taco_decode_resumable: slot_out is required when utterances are resumed or may be left unfinished");
+  if ((resume_slot || leave_unfinished) && !h->bat_ok) TACO_FAIL(TACO_EINVAL, "taco_decode_resumable: this model does not run on the lockstep decoder, which is the one that can leave utterances unfinished");
   if (B < 1) TACO_FAIL(TACO_EINVAL, "taco_decode: B = %d", B);
   // everything that sizes a memset or a launch is checked before anything is enqueued
   if (T_in < 1 || T_in > TACO_MAX_TIN) TACO_FAIL(TACO_EINVAL, "taco_decode: T_in = %d symbols is outside the decoder's capacity 1..%d", T_in, TACO_MAX_TIN);
@@ -447,6 +461,12 @@ extern "C" int taco_decode(taco_handle h, const float* memory, const float* proc
   // host round trip in between.
   // The lengths of a padded batch come to the host (one small copy and wait per call): they are checked, and in a
   // batch wider than one folded-context chunk every utterance short enough runs the faster one-chunk instance.
+  std::vector<int32_t> host_resume;
+  if (slot_out) TACO_HIP(hipMemsetAsync(slot_out, 0xff, sizeof(int32_t) * (size_t)B, s));      // -1: not left unfinished
+  if (resume_slot) {
+    host_resume.resize((size_t)B);
+    TACO_HIP(hipMemcpyAsync(host_resume.data(), resume_slot, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, s));
+  }
   std::vector<int32_t> host_lens;
   if (lens) {
     host_lens.resize((size_t)B);
@@ -466,11 +486,26 @@ extern "C" int taco_decode(taco_handle h, const float* memory, const float* proc
   }
   std::vector<int> fits;
   std::vector<int> rest;
+  bool resuming = false;
+  if (resume_slot) {
+    if (host_lens.empty()) TACO_HIP(hipStreamSynchronize(s));
+    unsigned taken = 0;
+    for (int b = 0; b < B; ++b) {
+      const int sl = host_resume[b];
+      if (sl < 0) continue;
+      const int own = host_lens.empty() ? T_in : host_lens[b];
+      if (sl >= TACO_BATCH_NB || ((taken >> sl) & 1u) || own > TACO_BT_TIN)
+        TACO_FAIL(TACO_EINVAL, "taco_decode_resumable: resume_slot[%d] = %d (a slot is 0..%d, taken once, and its utterance fits the lockstep decoder)", b, sl, TACO_BATCH_NB - 1);
+      taken |= 1u << sl;
+      resuming = true;
+    }
+  }
   for (int b = 0; b < B; ++b) {
     const int own = host_lens.empty() ? T_in : host_lens[b];
     if (h->bat_ok && own <= TACO_BT_TIN) fits.push_back(b);
     else rest.push_back(b);
   }
+  if (resuming || leave_unfinished) min_group = 1;      // saved state lives in the lockstep kernel only
   if ((int)fits.size() < min_group) {
     rest.insert(rest.end(), fits.begin(), fits.end());
     fits.clear();
@@ -479,7 +514,8 @@ extern "C" int taco_decode(taco_handle h, const float* memory, const float* proc
   if (!fits.empty()) {
     // one launch for all of them: the kernel itself walks the utterances in index order, skipping those beyond its capacity
     const int rc = taco_launch_decoder_batch(h, memory, processed_memory, T_in, lens, B, (int)fits.size(), n_launches, masks, T_cap,
-                                             max_steps, gate_threshold, forced_mel, mel, gate, align, n_frames, reached_max, s);
+                                             max_steps, gate_threshold, forced_mel, mel, gate, align, n_frames, reached_max,
+                                             resuming ? resume_slot : nullptr, leave_unfinished ? 1 : 0, slot_out, s);
     if (rc != TACO_OK) return rc;
     ++n_launches;
   }
@@ -493,7 +529,12 @@ extern "C" int taco_decode(taco_handle h, const float* memory, const float* proc
     if (rc != TACO_OK) return rc;
     ++n_launches;
   }
-  return taco_decoder_collect(h, n_launches, s);
+  const int crc = taco_decoder_collect(h, n_launches, s);
+  if (crc != TACO_OK) return crc;
+  // a lockstep launch (always the call's first) that left utterances unfinished: keep the prenet output they were about to consume
+  if (leave_unfinished && !fits.empty() && h->dec_ctl_host[0].reached_max == 2u)
+    return taco_decoder_batch_keep_prenet_output(h, (int)h->dec_ctl_host[0].n_frames, s);
+  return TACO_OK;
 }
 
 extern "C" int taco_postnet(taco_handle h, const float* mel, const int32_t* n_frames, int32_t B, int32_t T_cap,

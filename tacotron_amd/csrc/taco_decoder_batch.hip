@@ -126,6 +126,9 @@ constexpr int LQ_SRED = LQ_Q + QD;
 constexpr int LQ_U = LQ_SRED + 32;
 constexpr int LQ_END = LQ_U + TIN * QD;
 static_assert(NQ * TIN >= KH && NQ * TIN >= CPG * MEMW, "shared Q scratch area");
+constexpr int BT_CARRY_R = 10;                         // acc_a (4), acc_dn (4), c_a, c_d
+constexpr int BT_CARRY_Q = 2 * (TIN + 2 * HALO);       // LQ_AW .. the end of LQ_CUM
+static_assert(LQ_CUM == LQ_AW + TIN + 2 * HALO && LQ_Q == LQ_CUM + TIN + 2 * HALO, "the weights and cumulative weights are one block of LDS");
 constexpr int L_TOTAL = LP_END > LQ_END ? (LP_END > LM_END ? LP_END : LM_END) : (LQ_END > LM_END ? LQ_END : LM_END);
 static_assert(L_TOTAL * 4 <= 160 * 1024, "batched decoder LDS carve exceeds a CU's 160 KiB");
 
@@ -151,6 +154,14 @@ struct BatArgs {
   unsigned words_bytes;
   taco_bat_layout lay;
   taco_dec_ctl* ctl;
+  // Leaving utterances unfinished and taking them up again in a later launch (see "leaving and resuming" in the kernel)
+  const int32_t* resume;   // device [B] or NULL: the slot whose saved state utterance i continues, -1 = it starts anew
+  int leave;               // 1: end the launch once a slot has no successor, the running utterances' state goes to `carry_*`
+  float* carry_r;          // [workgroups][waves][64 lanes][BT_CARRY_R]: carried partial sums and cell states of every column
+  float* carry_q;          // [NB * NQ][BT_CARRY_Q]: a Q workgroup's attention weights and cumulative weights (with halos)
+  const uint32_t* carry_p; // [NB * KP] words, exchange layout: the prenet output the left utterances were about to consume
+  int32_t* carry_ctl;      // [NB]: frames a slot's utterance had produced when it was left
+  int32_t* slot_out;       // device [B]: the slot an utterance was left in (entries of finished utterances are not touched)
   unsigned long long* frame_clock;
   int frame_clock_cap;
 #ifdef TACO_BT_STAMPS
@@ -458,24 +469,45 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
   auto next_utterance = [&]() -> int {
     while (cursor < a.B) {
       const int i = cursor++;
-      if ((a.lens ? a.lens[i] : a.T_in) <= TIN) return i;
+      if ((a.lens ? a.lens[i] : a.T_in) <= TIN && !(a.resume && a.resume[i] >= 0)) return i;
     }
     return -1;
   };
   unsigned alive = 0;                          // slots holding an utterance that still produces frames
   unsigned waiting = 0;                        // slots whose next utterance is booked and starts at the coming multiple of four
-  int utt_u = 0, t0_u = 0;                     // my column's slot: its utterance, and the lockstep frame that one started in
-  {
-    int first = 0;
-    for (int sl = 0; sl < NB; ++sl) {
-      const int nu = next_utterance();
-      if (sl == 0) first = nu < 0 ? 0 : nu;
-      if (nu >= 0) alive |= 1u << sl;
-      if (utt == sl) utt_u = nu >= 0 ? nu : first;
+  int utt_u = -1, t0_u = 0;                    // my column's slot: its utterance, and the lockstep frame that one started in
+  // Leaving and resuming.  A launch told to `leave` ends as soon as a slot has no successor - at a lockstep frame that is
+  // a multiple of four, so that every running utterance has produced a multiple of four frames plus its start's - and
+  // saves what its running utterances carry from one frame to the next: per column the partial sums over the previous
+  // frame's vectors and the cell states, per Q workgroup the weights and cumulative weights; the prenet output they
+  // were about to consume stays in the exchange buffer (the host copies it aside).  A later launch that is given
+  // `resume` puts those utterances back into their slots at its frame 0 with a start frame of minus the frames they
+  // have: own frame indices, tag bits and arithmetic continue as if the launch had never ended.
+  unsigned carried = 0;
+  if (a.resume) {
+    for (int i = 0; i < a.B; ++i) {
+      const int sl = a.resume[i];
+      if (sl >= 0 && sl < NB) {
+        carried |= 1u << sl;
+        if (utt == sl) { utt_u = i; t0_u = -a.carry_ctl[sl]; }
+      }
     }
   }
+  alive = carried;
+  for (int sl = 0; sl < NB; ++sl) {
+    if ((carried >> sl) & 1u) continue;
+    const int nu = next_utterance();
+    if (nu >= 0) alive |= 1u << sl;
+    if (utt == sl) utt_u = nu;
+  }
+  {
+    // slots never filled run as copies of the first running utterance, unwritten
+    const int first = alive ? __builtin_amdgcn_readlane(utt_u, __builtin_ctz(alive)) : 0;
+    if (utt_u < 0) utt_u = first;
+  }
+  const bool col_carried = (carried >> utt) & 1u;
   int q_b = __builtin_amdgcn_readlane(utt_u, q_slot);     // Q: my slot's utterance, its start frame, its length
-  int q_t0 = 0;
+  int q_t0 = __builtin_amdgcn_readlane(t0_u, q_slot);
   int len = 0;
   if (tid < 16) {     // biases as [unit][gate]
     const int u = tid >> 2, gt = tid & 3, hu = j * 4 + u;
@@ -616,6 +648,13 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
   };
   if (is_q) fill_slot();
   __syncthreads();
+  const bool q_carried = is_q && ((carried >> q_slot) & 1u);
+  if (q_carried) {
+    // a resumed utterance: the weights it had when it was left (the location term follows below)
+    const float* src = a.carry_q + (size_t)q_id * BT_CARRY_Q;
+    for (int i = tid; i < BT_CARRY_Q; i += NT) lds[LQ_AW + i] = src[i];
+  }
+  __syncthreads();
   // (lane_o: the lane number behind a compiler barrier, taken anew every frame, see BT_OPQ.)
   // Taps are numbered 32 c + k (c = 0: previous weights, 1: cumulative weights; k >= K carries a zero filter value), so
   // that step m = 8 c + k / 4 reads weight number k of array c at a compile-time distance from one per-lane address:
@@ -673,6 +712,15 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
   f32x4 acc_dn = {0.0f, 0.0f, 0.0f, 0.0f};    // decoder-LSTM partial over the previous decoder hidden state
   float c_a = 0.0f, c_d = 0.0f;               // cell states (wave 0: lane = (unit kq, utterance utt))
   int t = 0;
+  int left = 0;                               // the launch ended with utterances left unfinished
+  float* carry_mine = a.carry_r + ((size_t)(j * NW + wave) * 64 + lane) * BT_CARRY_R;
+  if (q_carried) update_location_term(lane);  // (the barrier in front of the frame loop's first energies covers it)
+  if (col_carried) {
+    acc_a = f32x4{carry_mine[0], carry_mine[1], carry_mine[2], carry_mine[3]};
+    acc_dn = f32x4{carry_mine[4], carry_mine[5], carry_mine[6], carry_mine[7]};
+    c_a = carry_mine[8];
+    c_d = carry_mine[9];
+  }
   // word index of this lane's first load in each vector, replica `rep`
   const unsigned w_lane_h1 = (unsigned)(a.lay.h1 + rep * a.lay.h1_cap) + bt_word(16 * (wave * NL_P) + 4 * kq, utt);
   const unsigned w_lane_p = (unsigned)(a.lay.p + rep * a.lay.p_cap) + bt_word(16 * (wave * NL_P) + 4 * kq, utt);
@@ -829,6 +877,7 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
       }
     }
     if ((alive | waiting) == 0u || t >= a.t_limit) break;
+    if (a.leave && t > 0 && (t & 3) == 0 && cursor >= a.B && ((alive | waiting) & 0xffffu) != 0xffffu) { left = 1; break; }
     BT_STAMP(1);
 
     // ============ attention LSTM ============
@@ -849,6 +898,12 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
         if (t == 0 || ((fresh >> utt) & 1u)) {
 #pragma unroll
           for (int i = 0; i < NL_P; ++i) v[i] = u32x4{0u, 0u, 0u, 0u};
+        }
+        if (t == 0 && col_carried && t0_u != 0) {      // a resumed utterance: the prenet output it was about to consume when it
+                                                       // was left (one that was left before its first frame starts from zeros)
+          const u32x4* src = reinterpret_cast<const u32x4*>(a.carry_p + bt_word(16 * (wave * NL_P) + 4 * kq, utt));
+#pragma unroll
+          for (int i = 0; i < NL_P; ++i) v[i] = src[64 * i];
         }
       }
       BT_STAMP(2);
@@ -1366,9 +1421,26 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
   else if (is_q) frame_loop(std::integral_constant<int, 3>{});
   else frame_loop(std::integral_constant<int, 0>{});
 
+  if (left) {
+    // what the running utterances carry into their next frame (every column's: the columns of idle slots are not used)
+    carry_mine[0] = acc_a[0]; carry_mine[1] = acc_a[1]; carry_mine[2] = acc_a[2]; carry_mine[3] = acc_a[3];
+    carry_mine[4] = acc_dn[0]; carry_mine[5] = acc_dn[1]; carry_mine[6] = acc_dn[2]; carry_mine[7] = acc_dn[3];
+    carry_mine[8] = c_a;
+    carry_mine[9] = c_d;
+    if (is_q) {
+      float* dst = a.carry_q + (size_t)q_id * BT_CARRY_Q;
+      for (int i = tid; i < BT_CARRY_Q; i += NT) dst[i] = lds[LQ_AW + i];
+    }
+    if (j == 0 && wave == 0 && lane < NB && ((alive >> lane) & 1u)) {
+      a.carry_ctl[lane] = t - t0_u;
+      a.n_frames[utt_u] = t - t0_u;        // frames so far
+      a.reached[utt_u] = (uint8_t)2u;      // 2 = left unfinished
+      a.slot_out[utt_u] = lane;
+    }
+  }
   if (j == 0 && tid == 0) {
     a.ctl->n_frames = (uint32_t)t;       // lockstep frames of the launch
-    a.ctl->reached_max = 0u;
+    a.ctl->reached_max = left ? 2u : 0u;
   }
 }
 
@@ -1413,6 +1485,15 @@ int taco_decoder_batch_pack(taco_handle h) {
 }
 
 size_t taco_decoder_batch_lds_bytes() { return (size_t)L_TOTAL * sizeof(float); }
+
+// After a launch that left utterances unfinished at lockstep frame `t_left`: the prenet output they were about to consume
+// (published at that frame's top, replica 0 of that frame's parity block) goes from the exchange buffer to the carry area.
+int taco_decoder_batch_keep_prenet_output(taco_handle h, int t_left, hipStream_t s) {
+  const size_t words_r = (size_t)TACO_BT_WGS * NW * 64 * BT_CARRY_R + (size_t)NB * NQ * BT_CARRY_Q;
+  const uint32_t* src = h->bat_gran + (size_t)(t_left & 1) * h->bat_lay.per_parity + h->bat_lay.p;
+  TACO_HIP(hipMemcpyAsync(h->bat_carry + words_r, src, sizeof(uint32_t) * (size_t)NB * KP, hipMemcpyDeviceToDevice, s));
+  return TACO_OK;
+}
 
 void taco_decoder_batch_fill_layout(taco_bat_layout* lay) {
   int off = 0;
@@ -1527,10 +1608,15 @@ void taco_decoder_batch_dump_stamps(int n_frames) {
 
 // One lockstep launch for all utterances of a call that fit the kernel (own length <= TACO_BT_TIN; `n_fit` of the B,
 // counted by the caller): sixteen at a time, a slot taking the next one as soon as its utterance has stopped.
+size_t taco_decoder_batch_carry_floats() {
+  // per column partial sums and cell states | per Q workgroup weights and cumulative weights | the prenet output vector (words)
+  return (size_t)TACO_BT_WGS * NW * 64 * BT_CARRY_R + (size_t)NB * NQ * BT_CARRY_Q + (size_t)NB * KP + 64;
+}
+
 int taco_launch_decoder_batch(taco_handle h, const float* memory, const float* pm, int T_in, const int32_t* lens,
                               int B, int n_fit, int group, const uint8_t* masks, int T_cap, int max_steps, float thr,
                               const float* forced_mel, float* mel, float* gate, float* align, int32_t* n_frames,
-                              uint8_t* reached, hipStream_t s) {
+                              uint8_t* reached, const int32_t* resume, int leave, int32_t* slot_out, hipStream_t s) {
   const taco_dims& d = h->d;
   if (n_fit < 1 || n_fit > B) TACO_FAIL(TACO_EINVAL, "lockstep launch for %d of %d utterances", n_fit, B);
   if (!lens && T_in > TIN) TACO_FAIL(TACO_EINVAL, "lockstep launch: T_in = %d without lengths (capacity %d)", T_in, TIN);
@@ -1555,6 +1641,14 @@ int taco_launch_decoder_batch(taco_handle h, const float* memory, const float* p
   a.words = h->bat_gran; a.lay = h->bat_lay;
   a.words_bytes = (unsigned)taco_decoder_batch_handoff_bytes();
   a.ctl = h->dec_ctl + group;
+  a.resume = resume;
+  a.leave = leave;
+  a.carry_r = h->bat_carry;
+  a.carry_q = a.carry_r + (size_t)TACO_BT_WGS * NW * 64 * BT_CARRY_R;
+  a.carry_p = reinterpret_cast<const uint32_t*>(a.carry_q + (size_t)NB * NQ * BT_CARRY_Q);
+  a.carry_ctl = reinterpret_cast<int32_t*>(const_cast<uint32_t*>(a.carry_p) + (size_t)NB * KP);
+  a.slot_out = slot_out;
+  if ((resume || leave) && !slot_out) TACO_FAIL(TACO_EINVAL, "lockstep launch that leaves or resumes utterances needs slot_out");
   a.frame_clock = group == 0 ? h->frame_clock : nullptr;
   a.frame_clock_cap = h->frame_clock_cap;
   TACO_HIP(hipMemsetAsync(h->bat_gran, 0, a.words_bytes, s));

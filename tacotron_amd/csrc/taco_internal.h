@@ -132,6 +132,7 @@ struct taco_handle_s {
   uint32_t* bat_gran;        // lockstep decoder hand-off words, 2 parities (NULL when the model exceeds its capacities)
   taco_bat_layout bat_lay;
   float* bat_wstream;        // attention-LSTM input columns in the lockstep kernel's streaming order
+  float* bat_carry;          // state of the utterances a lockstep launch left unfinished (taco_decode_resumable)
   int bat_ok;                // the lockstep kernel can run this model
   int bat_bf16;              // its LSTM gate rows are held and multiplied as bf16 (taco_set_precision)
   taco_dec_ctl* dec_ctl;     // device, one block per launch of a taco_decode call (grow-only)
@@ -182,7 +183,9 @@ int taco_decoder_collect(taco_handle h, int n_launches, hipStream_t s);
 int taco_launch_decoder_batch(taco_handle h, const float* memory, const float* pm, int T_in, const int32_t* lens,
                               int B, int n_fit, int launch_idx, const uint8_t* masks, int T_cap, int max_steps, float thr,
                               const float* forced_mel, float* mel, float* gate, float* align, int32_t* n_frames,
-                              uint8_t* reached, hipStream_t s);
+                              uint8_t* reached, const int32_t* resume, int leave, int32_t* slot_out, hipStream_t s);
+size_t taco_decoder_batch_carry_floats();
+int taco_decoder_batch_keep_prenet_output(taco_handle h, int t_left, hipStream_t s);
 size_t taco_decoder_batch_lds_bytes();
 size_t taco_decoder_batch_handoff_bytes();
 void taco_decoder_batch_fill_layout(taco_bat_layout* lay);

@@ -153,7 +153,12 @@ class Tacotron2:
 
   def decode(self, memory: torch.Tensor, pm: torch.Tensor, lens: Optional[torch.Tensor], masks: torch.Tensor,
              max_steps: int, forced_mel: Optional[torch.Tensor] = None, T_cap: Optional[int] = None,
-             want_align: bool = True, gate_threshold: Optional[float] = None):
+             want_align: bool = True, gate_threshold: Optional[float] = None,
+             resume_slots: Optional[torch.Tensor] = None, leave_unfinished: bool = False):
+    """The decoder stage.  Returns ``(mel, gate, align, n_frames, reached)``; with ``resume_slots`` or
+    ``leave_unfinished`` (``taco_decode_resumable``: a call may end while utterances are still running and a later call
+    takes them up again, see include/taco.h) a sixth element, ``slots`` [B] int32: -1, or the slot an utterance was left
+    in (its ``reached`` is 2 and its ``n_frames`` the frames it has so far)."""
     h = self._require()
     B, T, _ = memory.shape
     T_cap = int(T_cap or max_steps)
@@ -172,10 +177,20 @@ class Tacotron2:
         raise ValueError("forced_mel must be [B, n_mel, T_cap]")
     thr = self.gate_threshold if gate_threshold is None else float(gate_threshold)
     p = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
-    _lib.check(_lib.lib().taco_decode(
+    if resume_slots is None and not leave_unfinished:
+      _lib.check(_lib.lib().taco_decode(
+        h, p(memory.contiguous()), p(pm.contiguous()), p(ln), B, T, p(masks), T_cap, int(max_steps), C.c_float(thr),
+        p(forced_mel), p(mel), p(gate), p(align), p(n_frames), p(reached), self._stream()))
+      return mel, gate, align, n_frames, reached
+    rs = None if resume_slots is None else resume_slots.to(device=self.device, dtype=torch.int32).contiguous()
+    if rs is not None and tuple(rs.shape) != (B,):
+      raise ValueError("resume_slots must be [B]")
+    slots = torch.empty(B, device=self.device, dtype=torch.int32)
+    _lib.check(_lib.lib().taco_decode_resumable(
       h, p(memory.contiguous()), p(pm.contiguous()), p(ln), B, T, p(masks), T_cap, int(max_steps), C.c_float(thr),
-      p(forced_mel), p(mel), p(gate), p(align), p(n_frames), p(reached), self._stream()))
-    return mel, gate, align, n_frames, reached
+      p(forced_mel), p(mel), p(gate), p(align), p(n_frames), p(reached), p(rs), 1 if leave_unfinished else 0, p(slots),
+      self._stream()))
+    return mel, gate, align, n_frames, reached, slots
 
   def postnet(self, mel: torch.Tensor, n_frames: Optional[torch.Tensor]) -> torch.Tensor:
     h = self._require()
@@ -221,6 +236,45 @@ class Tacotron2:
     return (ticks[1:] - ticks[:-1]).to(torch.float64) * 0.01
 
   # ---- whole path ------------------------------------------------------------------------------
+  supports_resume = True     # decode() can leave utterances unfinished and take them up again (taco_decode_resumable)
+
+  def inference_batch_resumable(self, symbols: torch.Tensor, stresses: Optional[torch.Tensor], tones: Optional[torch.Tensor],
+                                durations: Optional[torch.Tensor], speakers: Optional[torch.Tensor], lens: torch.Tensor,
+                                max_decoder_steps: int, carried: Sequence[Tuple[int, int, torch.Tensor, torch.Tensor, Optional[torch.Tensor]]],
+                                leave_unfinished: bool, want_align: bool = True):
+    """``inference_batch`` for a caller that decodes many batches in a row and does not want each to end with a tail of
+    mostly empty decoder slots: with ``leave_unfinished`` the decoder stops as soon as a slot has no successor; the
+    utterances still running come back with ``reached == 2``, their frames so far and the slot that holds their state.
+    The caller makes them the first rows of its next batch and describes them in ``carried``, one
+    ``(slot, frames so far, mel row [n_mel, T_cap], gate row [T_cap], alignment row [T_cap, >= len] or None)`` per row:
+    they go on from their next frame - bit for bit as if never interrupted - and their earlier columns are copied in.
+    The postnet skips the rows left unfinished.  ``max_decoder_steps`` must be positive.
+    Returns ``(mel, mel_postnet, gate, alignments, n_frames, reached, slots)``."""
+    if int(max_decoder_steps) <= 0:
+      raise ValueError("leaving utterances unfinished needs a step limit")
+    ids = [t for t in (symbols, stresses, tones, durations) if t is not None]
+    B = symbols.shape[0]
+    memory, pm = self.encode(ids, speakers, lens)
+    cap = int(max_decoder_steps)
+    mk = self.masks_from_global_rng(cap)
+    resume = None
+    if carried:
+      resume = torch.full((B,), -1, dtype=torch.int32)
+      for b, row in enumerate(carried):
+        resume[b] = int(row[0])
+    mel, gate, align, n_frames, reached, slots = self.decode(memory, pm, lens, mk, cap, want_align=want_align,
+                                                            resume_slots=resume, leave_unfinished=leave_unfinished)
+    for b, (_, n0, mel_row, gate_row, align_row) in enumerate(carried):      # what earlier calls produced of these rows
+      if n0 > 0:
+        mel[b, :, :n0] = mel_row[:, :n0]
+        gate[b, :n0] = gate_row[:n0]
+        if align is not None and align_row is not None:
+          w = min(align.shape[2], align_row.shape[1])
+          align[b, :n0, :w] = align_row[:n0, :w]
+    done = torch.where(reached == 2, torch.zeros_like(n_frames), n_frames)
+    post = self.postnet(mel, done)
+    return mel, post, gate, align, n_frames, reached, slots
+
   def inference_batch(self, symbols: torch.Tensor, stresses: Optional[torch.Tensor], tones: Optional[torch.Tensor],
                       durations: Optional[torch.Tensor], speakers: Optional[torch.Tensor],
                       lens: Optional[torch.Tensor], max_decoder_steps: int, masks: Optional[torch.Tensor] = None,

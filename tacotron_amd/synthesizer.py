@@ -266,12 +266,20 @@ class Synthesizer:
 
   def launch_batch(self, lines: Sequence[Sequence[str]], speaker: Optional[str], max_decoder_steps: int = 3000,
                    seed: int = 0, include_stats: bool = False, keep_on_device: bool = False,
-                   prepared: Optional[List[_Prepared]] = None) -> "_PendingBatch":
+                   prepared: Optional[List[_Prepared]] = None, tags: Optional[Sequence[object]] = None,
+                   carry: Optional[List["_Unfinished"]] = None, leave_unfinished: bool = False) -> "_PendingBatch":
     """The device half of ``infer_batch``: encoder, decoder (the call returns when the decoder has finished), postnet
     and the copies to the host are enqueued, the copies are NOT waited for.  ``finish_batch`` waits for them and cuts
     the batch into per-line results - a caller with many batches runs it on another thread while this thread launches
-    the next batch, so the GPU does not idle while the host slices and writes."""
-    preps = prepared if prepared is not None else self.prepare_batch(lines, speaker)
+    the next batch, so the GPU does not idle while the host slices and writes.
+    ``leave_unfinished`` / ``carry`` (models with ``supports_resume``): the decoder stops as soon as one of its sixteen
+    slots has no successor instead of running the batch's last lines to their end with the other slots empty; the
+    lines still running are in ``pending.unfinished`` and go into the next launch as its ``carry``, where they continue
+    from their next frame (bit for bit as if never interrupted).  ``tags`` name the lines (default: their index);
+    ``pending.finished_tags`` are those of the results ``finish_batch`` returns."""
+    carry = list(carry or [])
+    preps = [u.prep for u in carry] + list(prepared if prepared is not None else self.prepare_batch(lines, speaker))
+    all_tags = [u.tag for u in carry] + list(tags if tags is not None else range(len(preps) - len(carry)))
     lens = [len(p.ids["symbols"]) for p in preps]
     T = max(lens)
     init_global_seeds(seed)
@@ -289,18 +297,29 @@ class Synthesizer:
       speakers = torch.full((len(preps), T), preps[0].speaker_id, dtype=torch.int64, device=self.device)
     lens_t = torch.tensor(lens, dtype=torch.int32, device=self.device)
     start = time.perf_counter()
-    mel, post, gate, align, n_frames, reached = self.model.inference_batch(
-      padded("symbols"), padded("stresses"), padded("tones"), padded("durations"), speakers, lens_t,
-      max_decoder_steps, want_align=include_stats)
-    # (the decoder has finished - its call waits for it -, so the frame counts are final; the postnet is still running)
+    slots = None
+    if carry or leave_unfinished:
+      mel, post, gate, align, n_frames, reached, slots = self.model.inference_batch_resumable(
+        padded("symbols"), padded("stresses"), padded("tones"), padded("durations"), speakers, lens_t, max_decoder_steps,
+        [(u.slot, u.n_frames, u.mel, u.gate, u.align) for u in carry], leave_unfinished, want_align=include_stats)
+      slots = slots.cpu().tolist()
+    else:
+      mel, post, gate, align, n_frames, reached = self.model.inference_batch(
+        padded("symbols"), padded("stresses"), padded("tones"), padded("durations"), speakers, lens_t,
+        max_decoder_steps, want_align=include_stats)
+    # (the decoder has finished - its call waits for it -, so the frame counts are final)
     n_frames = n_frames.cpu().tolist()
     reached = reached.cpu().tolist()
     pending = _PendingBatch(self, preps, lens, n_frames, reached, include_stats, keep_on_device, start)
+    pending.rows = [b for b in range(len(preps)) if reached[b] != 2]
+    pending.finished_tags = [all_tags[b] for b in pending.rows]
+    pending.unfinished = [_Unfinished(all_tags[b], preps[b], slots[b], n_frames[b], mel[b], gate[b], None if align is None else align[b])
+                          for b in range(len(preps)) if reached[b] == 2]
     if keep_on_device:
       pending.arrays = (post, mel, gate, align)
       return pending
-    # one copy per array for the whole batch (up to its longest utterance), sliced per line on the host
-    n_max = max(n_frames)
+    # one copy per array for the whole batch (up to its longest finished utterance), sliced per line on the host
+    n_max = max([n_frames[b] for b in pending.rows] or [1])
     staging = self._staging_pool().get()
     pending.staging = staging
     post_h = self._to_host(post[:, :, :n_max], 0, staging, wait=False)
@@ -326,7 +345,8 @@ class Synthesizer:
     post, mel, gate, align = pending.arrays
     on_device = pending.keep_on_device
     out = []
-    for b, p in enumerate(pending.preps):
+    for b in pending.rows:                      # (rows left unfinished come back with a later batch)
+      p = pending.preps[b]
       n = pending.n_frames[b]
       res = self._result(p, post[b, :, :n], bool(pending.reached[b]), seconds)
       if pending.include_stats:
@@ -335,6 +355,18 @@ class Synthesizer:
         res.alignments = align[b, :n, :pending.lens[b]]
       out.append(res)
     return out
+
+
+@dataclass
+class _Unfinished:
+  """A line a launch left unfinished: what the next launch needs to take it up again."""
+  tag: object
+  prep: _Prepared
+  slot: int
+  n_frames: int
+  mel: torch.Tensor                      # [n_mel, T_cap] row of the launch that left it (frames so far)
+  gate: torch.Tensor                     # [T_cap]
+  align: Optional[torch.Tensor]          # [T_cap, T_in of that launch] or None
 
 
 class _PendingBatch:
@@ -347,6 +379,9 @@ class _PendingBatch:
     self.arrays = None
     self.copied = None
     self.keep = None
+    self.rows: List[int] = list(range(len(preps)))      # rows whose utterances have finished
+    self.finished_tags: List[object] = list(range(len(preps)))
+    self.unfinished: List["_Unfinished"] = []
 
   def release(self) -> None:
     """Gives the batch's staging set back (its result arrays must not be used afterwards)."""

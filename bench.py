@@ -297,10 +297,9 @@ def batch64_record(model, ckpt, device, frames=600, reps=3, pmc_pattern="r*[0-9a
                                "the launch stream); exact-f32 matrix-core products run at the f32 vector rate, 1/16 of the bf16 rate"}}
 
 
-def lines_workload(model, ckpt, device, world, rank, lines_per_gpu, frames, batch_size, live_stop=False):
+def lines_workload(model, ckpt, device, world, rank, lines_per_gpu, frames, batch_size):
   """The batch-synthesis configuration: world x lines_per_gpu synthetic lines, LPT-sharded over the ranks; returns
-  (step function, frames of this rank per step, frames of the job per step, description).  live_stop: the stop test
-  decides (a checkpoint with a calibrated stop token; the step function then returns the frames it produced)."""
+  (step function, frames of this rank per step, frames of the job per step, description)."""
   from tacotron_amd import scenarios, sharding
   from tacotron_amd.masks import prenet_keep_masks
   n_lines = world * lines_per_gpu
@@ -317,18 +316,14 @@ def lines_workload(model, ckpt, device, world, rank, lines_per_gpu, frames, batc
                     d(ids["speakers"]), d(ids["lens"])))
 
   def step():
-    out, counts = None, []
+    out = None
     for chans, spk, ln in batches:
       mem, pm = model.encode(chans, spk, ln)
-      mel, gate, align, nf, reached = model.decode(mem, pm, ln, masks, frames, gate_threshold=None if live_stop else 2.0,
-                                                   want_align=False)
+      mel, gate, align, nf, reached = model.decode(mem, pm, ln, masks, frames, gate_threshold=2.0, want_align=False)
       out = model.postnet(mel, nf)
-      counts.append(nf)
-    return int(torch.cat(counts).sum()) if live_stop else out
+    return out
 
-  desc = (f"{n_lines} synthetic lines (T_in ~ U{{20..200}}, seed 2024), "
-          + (f"stop test live (calibrated stop token), at most {frames} decoder frames each, " if live_stop else
-             f"{frames} decoder frames each (stop disabled), ") +
+  desc = (f"{n_lines} synthetic lines (T_in ~ U{{20..200}}, seed 2024), {frames} decoder frames each (stop disabled), "
           f"partitioned longest-processing-time-first over {world} rank(s), padded batches of {batch_size} "
           "(lockstep decoder, one persistent launch per batch, 16 utterances in flight), encoder + decoder + postnet")
   return step, len(mine) * frames, n_lines * frames, desc
@@ -570,25 +565,46 @@ def main():
     out["lines_one_gpu"] = {"workload": ldesc, "value": round(ljob / lsec, 1), "unit": "mel frames/s",
                             "ms_per_step": round(lsec * 1e3, 3), "steps": 3,
                             "note": "same as `python bench.py --workload lines`; runs with --gpus N > 1 measure this workload"}
-    # ... and the same lines with the stop test deciding (the calibrated stop token of the parity tests' checkpoint):
-    # utterances end at different frames, slots refill, every call ends with a drain
+    # ... and lines whose stop test decides (the calibrated stop token of the parity tests' checkpoint; symbols drawn as
+    # scripts/bulk_once.py draws them), through the product's own batch path, Synthesizer.launch_batch / finish_batch:
+    # lines end at different frames, slots refill, and every launch but the last leaves its running lines to the next
     try:
+      from tacotron_amd.synthesizer import Synthesizer
       with open(os.path.join(ROOT, "tests", "golden", "gate_bias.json")) as f:
         ckpt_stop = scenarios.checkpoint("ljs", json.load(f)["ljs"])
-      model_stop = Tacotron2(hp, **abi.mapping_counts(ckpt_stop, hp))
-      model_stop.load_state_dict(ckpt_stop["model_state"])
-      model_stop.to(device)
-      sstep, _, _, sdesc = lines_workload(model_stop, ckpt_stop, device, 1, 0, args.lines_per_gpu, frames, args.batch_size,
-                                          live_stop=True)
+      synth = Synthesizer(ckpt_stop, device=device)
+      keys = sorted(k for k in ckpt_stop["symbol_mapping"].keys() if k and "|" not in k and k.strip() == k)
+      r = np.random.RandomState(2024)
+      text = [[keys[i] for i in r.randint(0, len(keys), size=int(t))] for t in r.randint(20, 201, size=4 * args.lines_per_gpu)]
+      order = sorted(range(len(text)), key=lambda i: -len(text[i]))
+      groups = [order[i:i + args.batch_size] for i in range(0, len(order), args.batch_size)]
+      speaker = next(iter(ckpt_stop["speaker_mapping"]))
+      preps = [synth.prepare_batch([text[i] for i in g], speaker) for g in groups]
+
+      def sstep():
+        produced, carry = 0, []
+        for g, grp in enumerate(groups):
+          pend = synth.launch_batch([text[i] for i in grp], speaker, frames, 1111, prepared=preps[g], tags=grp, carry=carry,
+                                    leave_unfinished=g + 1 < len(groups))
+          carry = pend.unfinished
+          produced += sum(res.mel_outputs_postnet.shape[1] for res in synth.finish_batch(pend))
+          pend.release()
+        return produced
+
       sstep()
       torch.cuda.synchronize(device)
       t0 = time.perf_counter()
-      produced = sum(sstep() for _ in range(3))
+      produced = sum(sstep() for _ in range(2))
       torch.cuda.synchronize(device)
       ssec = time.perf_counter() - t0
-      out["lines_one_gpu_live_stop"] = {"workload": sdesc, "value": round(produced / ssec, 1), "unit": "mel frames/s",
-                                        "frames_per_step": produced // 3, "ms_per_step": round(ssec / 3 * 1e3, 3), "steps": 3}
-      model_stop.close()
+      out["lines_one_gpu_live_stop"] = {
+        "workload": f"{len(text)} synthetic lines (T_in ~ U{{20..200}}), stop test live (calibrated stop token), at most {frames} decoder "
+                    f"frames each, padded batches of {args.batch_size} through Synthesizer.launch_batch / finish_batch (host logic and "
+                    "copies to the host included, symbol mapping done beforehand, nothing written to disk); every launch but the last "
+                    "leaves the lines still running to the next one (taco_decode_resumable)",
+        "value": round(produced / ssec, 1), "unit": "mel frames/s", "frames_per_step": produced // 2,
+        "ms_per_step": round(ssec / 2 * 1e3, 3), "steps": 2}
+      synth.model.close()
     except (OSError, KeyError, ValueError) as ex:
       out["lines_one_gpu_live_stop"] = {"skipped": str(ex)}
   if rank == 0 and world == 1 and args.cpu_seconds > 0:

@@ -238,42 +238,64 @@ class Tacotron2:
   # ---- whole path ------------------------------------------------------------------------------
   supports_resume = True     # decode() can leave utterances unfinished and take them up again (taco_decode_resumable)
 
-  def inference_batch_resumable(self, symbols: torch.Tensor, stresses: Optional[torch.Tensor], tones: Optional[torch.Tensor],
-                                durations: Optional[torch.Tensor], speakers: Optional[torch.Tensor], lens: torch.Tensor,
-                                max_decoder_steps: int, carried: Sequence[Tuple[int, int, torch.Tensor, torch.Tensor, Optional[torch.Tensor]]],
-                                leave_unfinished: bool, want_align: bool = True):
+  def inference_batch_resumable(self, symbols: Optional[torch.Tensor], stresses: Optional[torch.Tensor], tones: Optional[torch.Tensor],
+                                durations: Optional[torch.Tensor], speakers: Optional[torch.Tensor], lens: Optional[torch.Tensor],
+                                max_decoder_steps: int, carried: Sequence[dict], leave_unfinished: bool, want_align: bool = True):
     """``inference_batch`` for a caller that decodes many batches in a row and does not want each to end with a tail of
     mostly empty decoder slots: with ``leave_unfinished`` the decoder stops as soon as a slot has no successor; the
     utterances still running come back with ``reached == 2``, their frames so far and the slot that holds their state.
-    The caller makes them the first rows of its next batch and describes them in ``carried``, one
-    ``(slot, frames so far, mel row [n_mel, T_cap], gate row [T_cap], alignment row [T_cap, >= len] or None)`` per row:
-    they go on from their next frame - bit for bit as if never interrupted - and their earlier columns are copied in.
+    The caller describes them in the next call's ``carried``, one dict per utterance with ``slot``, ``n_frames``,
+    ``length``, the rows ``memory`` [>= length, M] and ``processed_memory`` [>= length, A] this method returned for it
+    (the encoder is not run again: its output for a line may differ in the last bits from one batch to the next), and its
+    rows ``mel`` [n_mel, T_cap], ``gate`` [T_cap], ``align`` [T_cap, >= length] or None.  They are the first rows of this
+    call's results, go on from their next frame - bit for bit as if never interrupted - and their earlier columns are
+    copied in; the id tensors (``symbols`` ... ``lens``) hold the NEW utterances only (``symbols`` None: there are none).
     The postnet skips the rows left unfinished.  ``max_decoder_steps`` must be positive.
-    Returns ``(mel, mel_postnet, gate, alignments, n_frames, reached, slots)``."""
+    Returns ``(mel, mel_postnet, gate, alignments, n_frames, reached, slots, memory, processed_memory, lens)``."""
     if int(max_decoder_steps) <= 0:
       raise ValueError("leaving utterances unfinished needs a step limit")
-    ids = [t for t in (symbols, stresses, tones, durations) if t is not None]
-    B = symbols.shape[0]
-    memory, pm = self.encode(ids, speakers, lens)
+    n_old = len(carried)
+    mem_new = pm_new = None
+    if symbols is not None:
+      ids = [t for t in (symbols, stresses, tones, durations) if t is not None]
+      mem_new, pm_new = self.encode(ids, speakers, lens)
+    if n_old:
+      width = max([int(c["length"]) for c in carried] + ([mem_new.shape[1]] if mem_new is not None else []))
+      n_new = 0 if mem_new is None else mem_new.shape[0]
+      memory = torch.zeros(n_old + n_new, width, self.dims.M, device=self.device, dtype=torch.float32)
+      pm = torch.zeros(n_old + n_new, width, self.dims.A, device=self.device, dtype=torch.float32)
+      for b, c in enumerate(carried):
+        n = int(c["length"])
+        memory[b, :n] = c["memory"][:n]
+        pm[b, :n] = c["processed_memory"][:n]
+      if n_new:
+        memory[n_old:, :mem_new.shape[1]] = mem_new
+        pm[n_old:, :pm_new.shape[1]] = pm_new
+      old_lens = torch.tensor([int(c["length"]) for c in carried], dtype=torch.int32, device=self.device)
+      all_lens = old_lens if not n_new else torch.cat([old_lens, lens.to(device=self.device, dtype=torch.int32)])
+    else:
+      memory, pm, all_lens = mem_new, pm_new, lens
+    B = memory.shape[0]
     cap = int(max_decoder_steps)
     mk = self.masks_from_global_rng(cap)
     resume = None
-    if carried:
+    if n_old:
       resume = torch.full((B,), -1, dtype=torch.int32)
-      for b, row in enumerate(carried):
-        resume[b] = int(row[0])
-    mel, gate, align, n_frames, reached, slots = self.decode(memory, pm, lens, mk, cap, want_align=want_align,
+      for b, c in enumerate(carried):
+        resume[b] = int(c["slot"])
+    mel, gate, align, n_frames, reached, slots = self.decode(memory, pm, all_lens, mk, cap, want_align=want_align,
                                                             resume_slots=resume, leave_unfinished=leave_unfinished)
-    for b, (_, n0, mel_row, gate_row, align_row) in enumerate(carried):      # what earlier calls produced of these rows
+    for b, c in enumerate(carried):      # what earlier calls produced of these rows
+      n0 = int(c["n_frames"])
       if n0 > 0:
-        mel[b, :, :n0] = mel_row[:, :n0]
-        gate[b, :n0] = gate_row[:n0]
-        if align is not None and align_row is not None:
-          w = min(align.shape[2], align_row.shape[1])
-          align[b, :n0, :w] = align_row[:n0, :w]
+        mel[b, :, :n0] = c["mel"][:, :n0]
+        gate[b, :n0] = c["gate"][:n0]
+        if align is not None and c.get("align") is not None:
+          w = min(align.shape[2], c["align"].shape[1])
+          align[b, :n0, :w] = c["align"][:n0, :w]
     done = torch.where(reached == 2, torch.zeros_like(n_frames), n_frames)
     post = self.postnet(mel, done)
-    return mel, post, gate, align, n_frames, reached, slots
+    return mel, post, gate, align, n_frames, reached, slots, memory, pm, all_lens
 
   def inference_batch(self, symbols: torch.Tensor, stresses: Optional[torch.Tensor], tones: Optional[torch.Tensor],
                       durations: Optional[torch.Tensor], speakers: Optional[torch.Tensor],

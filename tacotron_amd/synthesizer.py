@@ -278,30 +278,33 @@ class Synthesizer:
     from their next frame (bit for bit as if never interrupted).  ``tags`` name the lines (default: their index);
     ``pending.finished_tags`` are those of the results ``finish_batch`` returns."""
     carry = list(carry or [])
-    preps = [u.prep for u in carry] + list(prepared if prepared is not None else self.prepare_batch(lines, speaker))
-    all_tags = [u.tag for u in carry] + list(tags if tags is not None else range(len(preps) - len(carry)))
+    new_preps = list(prepared if prepared is not None else self.prepare_batch(lines, speaker))
+    preps = [u.prep for u in carry] + new_preps
+    all_tags = [u.tag for u in carry] + list(tags if tags is not None else range(len(new_preps)))
     lens = [len(p.ids["symbols"]) for p in preps]
-    T = max(lens)
+    new_lens = lens[len(carry):]
+    T = max(new_lens) if new_lens else 0
     init_global_seeds(seed)
 
     def padded(name):
-      if preps[0].ids[name] is None:
+      if not new_preps or new_preps[0].ids[name] is None:
         return None
-      out = np.zeros((len(preps), T), dtype=np.int64)
-      for b, p in enumerate(preps):
-        out[b, :lens[b]] = p.ids[name]
+      out = np.zeros((len(new_preps), T), dtype=np.int64)
+      for b, p in enumerate(new_preps):
+        out[b, :new_lens[b]] = p.ids[name]
       return torch.from_numpy(out).to(self.device)
 
     speakers = None
-    if self.hparams.use_speaker_embedding:
-      speakers = torch.full((len(preps), T), preps[0].speaker_id, dtype=torch.int64, device=self.device)
-    lens_t = torch.tensor(lens, dtype=torch.int32, device=self.device)
+    if self.hparams.use_speaker_embedding and new_preps:
+      speakers = torch.full((len(new_preps), T), new_preps[0].speaker_id, dtype=torch.int64, device=self.device)
+    lens_t = torch.tensor(new_lens, dtype=torch.int32, device=self.device) if new_preps else None
     start = time.perf_counter()
-    slots = None
+    slots = memory = pm = None
     if carry or leave_unfinished:
-      mel, post, gate, align, n_frames, reached, slots = self.model.inference_batch_resumable(
+      mel, post, gate, align, n_frames, reached, slots, memory, pm, _ = self.model.inference_batch_resumable(
         padded("symbols"), padded("stresses"), padded("tones"), padded("durations"), speakers, lens_t, max_decoder_steps,
-        [(u.slot, u.n_frames, u.mel, u.gate, u.align) for u in carry], leave_unfinished, want_align=include_stats)
+        [dict(slot=u.slot, n_frames=u.n_frames, length=len(u.prep.ids["symbols"]), memory=u.memory, processed_memory=u.processed_memory,
+              mel=u.mel, gate=u.gate, align=u.align) for u in carry], leave_unfinished, want_align=include_stats)
       slots = slots.cpu().tolist()
     else:
       mel, post, gate, align, n_frames, reached = self.model.inference_batch(
@@ -313,7 +316,8 @@ class Synthesizer:
     pending = _PendingBatch(self, preps, lens, n_frames, reached, include_stats, keep_on_device, start)
     pending.rows = [b for b in range(len(preps)) if reached[b] != 2]
     pending.finished_tags = [all_tags[b] for b in pending.rows]
-    pending.unfinished = [_Unfinished(all_tags[b], preps[b], slots[b], n_frames[b], mel[b], gate[b], None if align is None else align[b])
+    pending.unfinished = [_Unfinished(all_tags[b], preps[b], slots[b], n_frames[b], mel[b], gate[b], None if align is None else align[b],
+                                      memory[b], pm[b])
                           for b in range(len(preps)) if reached[b] == 2]
     if keep_on_device:
       pending.arrays = (post, mel, gate, align)
@@ -367,6 +371,8 @@ class _Unfinished:
   mel: torch.Tensor                      # [n_mel, T_cap] row of the launch that left it (frames so far)
   gate: torch.Tensor                     # [T_cap]
   align: Optional[torch.Tensor]          # [T_cap, T_in of that launch] or None
+  memory: torch.Tensor                   # the encoder's output for the line, [T_in of that launch, M] (not computed again)
+  processed_memory: torch.Tensor         # [T_in of that launch, A]
 
 
 class _PendingBatch:

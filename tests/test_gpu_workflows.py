@@ -64,6 +64,48 @@ def test_bulk_synthesis_of_ragged_lines_in_batches_of_64(tmp_path, gate_table):
     np.testing.assert_allclose(got, want, atol=LONG_FREE_TOL, rtol=0, err_msg=f"line {nr}")
 
 
+def test_files_do_not_depend_on_the_batch_size(tmp_path, gate_table):
+  """The synthesize command in batch mode hands the lines a decoder launch leaves unfinished to the next launch.  Whatever
+  the batch size - 16 (a launch leaves up to fifteen lines, most lines cross a launch boundary, some two), 48, or one
+  launch for everything - every line must have the same number of frames and the same frames, the alignments and
+  pre-postnet frames of --include-stats included.  The decoder continues a left line bit for bit
+  (tests/test_gpu_resume.py); the encoder's output for a line depends on its batch in the last bits (convolutions of
+  small launches add their partial tiles in another order), which a free-running line of the random-weight model
+  amplifies with the frame index: 1e-4 on frames and 1e-3 on attention weights over the first 100 frames, the
+  free-running bounds of long lines (5e-3, 2e-2) over all 300.  A line taken up at the wrong frame, or with another
+  line's state, is off by orders of magnitude more."""
+  from tacotron_amd import cli
+  from tacotron_amd.checkpoint import save_checkpoint
+  ckpt = scenario_checkpoint("ljs", gate_table["ljs"])
+  path = tmp_path / "ljs_synthetic.pt"
+  save_checkpoint(ckpt, path)
+  lines, lens = _ragged_lines(ckpt, 150, 20, 200, seed=99)
+  text = tmp_path / "lines.txt"
+  text.write_text("\n".join(lines), encoding="UTF-8")
+  common = ["synthesize", str(path), str(text), "--sep", "|", "--custom-seed", "7", "--max-decoder-steps", "300", "--device", "cuda:0",
+            "--include-stats"]
+  for bs in (16, 48, 150):
+    ns = cli.build_parser().parse_args(common + ["-out", str(tmp_path / f"bs{bs}"), "--batch-size", str(bs)])
+    assert ns.handler(ns)
+  names = sorted(p.name for p in (tmp_path / "bs150").iterdir() if p.suffix == ".npy")
+  assert len(names) == 3 * 150
+  counts = set()
+  for name in names:
+    want = np.load(tmp_path / "bs150" / name)
+    for bs in (16, 48):
+      got = np.load(tmp_path / f"bs{bs}" / name)
+      assert got.shape == want.shape, f"{name}: {got.shape} at --batch-size {bs}, {want.shape} in one launch"
+      if "alignments" in name:                 # [frames, symbols]
+        np.testing.assert_allclose(got[:100], want[:100], atol=1e-3, rtol=0, err_msg=f"{name} at --batch-size {bs}")
+        np.testing.assert_allclose(got, want, atol=2e-2, rtol=0, err_msg=f"{name} at --batch-size {bs}")
+      else:                                    # [n_mel, frames]
+        np.testing.assert_allclose(got[:, :100], want[:, :100], atol=1e-4, rtol=0, err_msg=f"{name} at --batch-size {bs}")
+        np.testing.assert_allclose(got, want, atol=LONG_FREE_TOL, rtol=0, err_msg=f"{name} at --batch-size {bs}")
+    if "-1-" not in name and "-2-" not in name:
+      counts.add(want.shape[1])
+  assert len(counts) > 5                      # lines of many different frame counts
+
+
 def test_synthesize_grids_on_gpu_matches_oracle_backed_run(tmp_path):
   """synthesize-grids through the HIP library (reference: src/tacotron_cli/textgrid_inference.py:108-142): the files
   the same command writes with the CPU oracle as its model, one grid at a time and in a padded batch."""

@@ -105,10 +105,16 @@ __global__ __launch_bounds__(256) void taco_conv_kernel(const float* __restrict_
   const int b = blockIdx.z;
   // split > 1: `split` consecutive workgroups share an output tile, each with its own range of slabs (see the end of
   // the slab loop for how their partial tiles meet)
-  const int tile_t = split > 1 ? blockIdx.x / split : blockIdx.x;
-  const int ksl = split > 1 ? blockIdx.x % split : 0;
+  // layout & 4: the grid is (channel blocks, column tiles, utterances) instead of (column tiles x split, channel blocks,
+  // utterances).  Workgroups go to the eight XCDs round-robin in launch order, so what runs fastest through the grid decides
+  // what an XCD gets: with the column tiles there and 16 tiles of which a ragged batch fills only the first few, XCD 0 (tiles
+  // 0 and 8) has twice the work of XCD 7 (tiles 7 and 15, mostly past the utterances' ends).  Channel blocks are always
+  // all there: every XCD gets the same share of every utterance, and an XCD's L2 keeps the weights of its own blocks.
+  const bool by_block = layout & 4;
+  const int tile_t = by_block ? blockIdx.y : (split > 1 ? blockIdx.x / split : blockIdx.x);
+  const int ksl = (!by_block && split > 1) ? blockIdx.x % split : 0;
   const int t0 = tile_t * CV_TT;
-  const int co0 = blockIdx.y * CV_CO;
+  const int co0 = (by_block ? blockIdx.x : blockIdx.y) * CV_CO;
   const int len = lens ? min(lens[b], T) : T;      // (a length beyond the buffers' T columns is read as T)
   const float* in_b = in + (size_t)b * c_in * T;
   taco_f32x16 acc;
@@ -567,7 +573,11 @@ int taco_launch_conv(const float* in, float* out, const float* w, const float* b
   const int tiles_t = (T + CV_TT - 1) / CV_TT, tiles_co = (c_out + CV_CO - 1) / CV_CO;
   const int ci = taco_conv_ci(k);
   const int split = split_ws ? taco_conv_split_factor(tiles_t * tiles_co * B, (c_in + ci - 1) / ci, n_cu) : 1;
-  const dim3 grid(tiles_t * split, tiles_co, B);
+  dim3 grid(tiles_t * split, tiles_co, B);
+  if (split == 1 && tiles_t <= 65535) {          // (a grid's y extent ends at 65535)
+    grid = dim3(tiles_co, tiles_t, B);
+    layout |= 4;
+  }
   switch (k) {
 #define TACO_CONV_CASE(KS)                                                                          \
   case KS:                                                                                          \

@@ -582,7 +582,7 @@ def main():
       preps = [synth.prepare_batch([text[i] for i in g], speaker) for g in groups]
 
       def sstep():
-        produced, carry = 0, []
+        produced, carry = 0, None
         for g, grp in enumerate(groups):
           pend = synth.launch_batch([text[i] for i in grp], speaker, frames, 1111, prepared=preps[g], tags=grp, carry=carry,
                                     leave_unfinished=g + 1 < len(groups))

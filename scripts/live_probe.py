@@ -39,7 +39,7 @@ for name in ("encode", "decode", "postnet"):
 for rep in range(3):
   stage.clear()
   t_launch = t_finish = dec_dev = 0.0
-  produced, carry = 0, []
+  produced, carry = 0, None
   torch.cuda.synchronize(); t00 = time.perf_counter()
   for g, grp in enumerate(groups):
     t0 = time.perf_counter()

@@ -23,13 +23,14 @@ order = sorted(range(n_lines), key=lambda i: -len(lines[i]))
 one = s.infer_batch([lines[i] for i in order], spk, steps, 7, include_stats=True)
 want = {i: res for i, res in zip(order, one)}
 got, left_at = {}, {}
-carry = []
+carry = None
 groups = [order[i:i + bs] for i in range(0, n_lines, bs)]
 for g, grp in enumerate(groups):
   p = s.launch_batch([lines[i] for i in grp], spk, steps, 7, include_stats=True, tags=grp, carry=carry, leave_unfinished=g + 1 < len(groups))
   carry = p.unfinished
-  for u in carry:
-    left_at.setdefault(u.tag, []).append((g, u.slot, u.n_frames))
+  if carry:
+    for tag, slot, nf in zip(carry.tags, carry.rows.slots, carry.rows.n_frames):
+      left_at.setdefault(tag, []).append((g, slot, nf))
   for tag, res in zip(p.finished_tags, s.finish_batch(p)):
     res.mel_outputs_postnet = res.mel_outputs_postnet.copy(); res.mel_outputs = res.mel_outputs.copy(); res.alignments = res.alignments.copy()
     got[tag] = res

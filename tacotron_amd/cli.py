@@ -224,7 +224,7 @@ def synthesize_plan(synth, plan: Sequence[PlannedLine], speaker: Optional[str], 
       # those slots empty.  So every launch but the last stops as soon as a slot has no successor, and the lines still
       # running head the next launch, where they go on from their next frame (same frames as if never interrupted).
       resumable = pipelined and max_decoder_steps > 0 and getattr(getattr(synth, "model", None), "supports_resume", False)
-      carry: List[object] = []
+      carry = None
 
       for g, group_idx in enumerate(groups):
         if pipelined:

@@ -21,6 +21,18 @@ from tacotron_amd.config import HParams
 _UNLIMITED_START = 8192     # first capacity tried when max_decoder_steps == 0 (no limit)
 
 
+class CarriedRows:
+  """Utterances a resumable decode left unfinished, as the next call takes them: per utterance the slot that holds its
+  state, its frames so far and its length, and - stacked, one row per utterance - the encoder's output for it and what
+  has been written of its mel / gate / alignment rows.  ``rows`` are their indices in the call that left them."""
+
+  def __init__(self, slots: List[int], n_frames: List[int], lengths: List[int], rows: List[int], memory: torch.Tensor,
+               processed_memory: torch.Tensor, mel: torch.Tensor, gate: torch.Tensor, align: Optional[torch.Tensor]):
+    self.slots, self.n_frames, self.lengths, self.rows = slots, n_frames, lengths, rows
+    self.memory, self.processed_memory = memory, processed_memory        # [n, T_in of that call, M] / [n, T_in, A]
+    self.mel, self.gate, self.align = mel, gate, align                  # [n, n_mel, T_cap], [n, T_cap], [n, T_cap, T_in] or None
+
+
 class Tacotron2:
   def __init__(self, hparams: HParams, n_symbols: int, n_stresses: Optional[int], n_speakers: Optional[int],
                n_tones: Optional[int], n_durations: Optional[int]):
@@ -240,62 +252,75 @@ class Tacotron2:
 
   def inference_batch_resumable(self, symbols: Optional[torch.Tensor], stresses: Optional[torch.Tensor], tones: Optional[torch.Tensor],
                                 durations: Optional[torch.Tensor], speakers: Optional[torch.Tensor], lens: Optional[torch.Tensor],
-                                max_decoder_steps: int, carried: Sequence[dict], leave_unfinished: bool, want_align: bool = True):
+                                max_decoder_steps: int, carried: Optional["CarriedRows"], leave_unfinished: bool,
+                                want_align: bool = True):
     """``inference_batch`` for a caller that decodes many batches in a row and does not want each to end with a tail of
     mostly empty decoder slots: with ``leave_unfinished`` the decoder stops as soon as a slot has no successor; the
-    utterances still running come back with ``reached == 2``, their frames so far and the slot that holds their state.
-    The caller describes them in the next call's ``carried``, one dict per utterance with ``slot``, ``n_frames``,
-    ``length``, the rows ``memory`` [>= length, M] and ``processed_memory`` [>= length, A] this method returned for it
-    (the encoder is not run again: its output for a line may differ in the last bits from one batch to the next), and its
-    rows ``mel`` [n_mel, T_cap], ``gate`` [T_cap], ``align`` [T_cap, >= length] or None.  They are the first rows of this
-    call's results, go on from their next frame - bit for bit as if never interrupted - and their earlier columns are
-    copied in; the id tensors (``symbols`` ... ``lens``) hold the NEW utterances only (``symbols`` None: there are none).
-    The postnet skips the rows left unfinished.  ``max_decoder_steps`` must be positive.
-    Returns ``(mel, mel_postnet, gate, alignments, n_frames, reached, slots, memory, processed_memory, lens)``."""
+    utterances still running come back with ``reached == 2``, their frames so far, and - as ``carried_out`` - what the
+    next call needs to take them up again (``CarriedRows``: their slots, frame counts, lengths, and their rows of the
+    encoder's output and of mel / gate / alignments; the encoder is not run again for them: its output for a line may
+    differ in the last bits from one batch to the next).  Passed as the next call's ``carried`` they are the first rows
+    of that call's results, go on from their next frame - bit for bit as if never interrupted - with their earlier
+    columns in place; the id tensors (``symbols`` ... ``lens``) hold the NEW utterances only (``symbols`` None: there are
+    none).  The postnet skips the rows left unfinished.  ``max_decoder_steps`` must be positive.
+    Returns ``(mel, mel_postnet, gate, alignments, n_frames, reached, carried_out)`` with ``n_frames`` / ``reached``
+    as lists (the call has waited for the decoder anyway) and ``carried_out`` None when every utterance has finished."""
     if int(max_decoder_steps) <= 0:
       raise ValueError("leaving utterances unfinished needs a step limit")
-    n_old = len(carried)
+    n_old = 0 if carried is None else len(carried.slots)
     mem_new = pm_new = None
     if symbols is not None:
       ids = [t for t in (symbols, stresses, tones, durations) if t is not None]
       mem_new, pm_new = self.encode(ids, speakers, lens)
+    new_lens = [] if lens is None or symbols is None else [int(v) for v in lens.tolist()]
+    if symbols is not None and lens is None:
+      new_lens = [symbols.shape[1]] * symbols.shape[0]
     if n_old:
-      width = max([int(c["length"]) for c in carried] + ([mem_new.shape[1]] if mem_new is not None else []))
       n_new = 0 if mem_new is None else mem_new.shape[0]
+      w_old = carried.memory.shape[1]
+      width = max(w_old, mem_new.shape[1] if n_new else 0)
       memory = torch.zeros(n_old + n_new, width, self.dims.M, device=self.device, dtype=torch.float32)
       pm = torch.zeros(n_old + n_new, width, self.dims.A, device=self.device, dtype=torch.float32)
-      for b, c in enumerate(carried):
-        n = int(c["length"])
-        memory[b, :n] = c["memory"][:n]
-        pm[b, :n] = c["processed_memory"][:n]
+      memory[:n_old, :w_old] = carried.memory
+      pm[:n_old, :w_old] = carried.processed_memory
       if n_new:
         memory[n_old:, :mem_new.shape[1]] = mem_new
         pm[n_old:, :pm_new.shape[1]] = pm_new
-      old_lens = torch.tensor([int(c["length"]) for c in carried], dtype=torch.int32, device=self.device)
-      all_lens = old_lens if not n_new else torch.cat([old_lens, lens.to(device=self.device, dtype=torch.int32)])
+      all_lens = list(carried.lengths) + new_lens
     else:
-      memory, pm, all_lens = mem_new, pm_new, lens
+      memory, pm, all_lens = mem_new, pm_new, new_lens
     B = memory.shape[0]
     cap = int(max_decoder_steps)
     mk = self.masks_from_global_rng(cap)
     resume = None
     if n_old:
-      resume = torch.full((B,), -1, dtype=torch.int32)
-      for b, c in enumerate(carried):
-        resume[b] = int(c["slot"])
-    mel, gate, align, n_frames, reached, slots = self.decode(memory, pm, all_lens, mk, cap, want_align=want_align,
+      resume = torch.tensor(list(carried.slots) + [-1] * (B - n_old), dtype=torch.int32)
+    lens_dev = torch.tensor(all_lens, dtype=torch.int32, device=self.device)
+    mel, gate, align, n_frames, reached, slots = self.decode(memory, pm, lens_dev, mk, cap, want_align=want_align,
                                                             resume_slots=resume, leave_unfinished=leave_unfinished)
-    for b, c in enumerate(carried):      # what earlier calls produced of these rows
-      n0 = int(c["n_frames"])
-      if n0 > 0:
-        mel[b, :, :n0] = c["mel"][:, :n0]
-        gate[b, :n0] = c["gate"][:n0]
-        if align is not None and c.get("align") is not None:
-          w = min(align.shape[2], c["align"].shape[1])
-          align[b, :n0, :w] = c["align"][:n0, :w]
+    if n_old:       # what earlier calls produced of these rows: one masked copy per array (this call wrote columns n0..)
+      n0 = torch.tensor(carried.n_frames, dtype=torch.int32, device=self.device)
+      earlier = torch.arange(cap, device=self.device, dtype=torch.int32)[None, :] < n0[:, None]
+      mel[:n_old] = torch.where(earlier[:, None, :], carried.mel, mel[:n_old])
+      gate[:n_old] = torch.where(earlier, carried.gate, gate[:n_old])
+      if align is not None and carried.align is not None:
+        w = min(align.shape[2], carried.align.shape[2])
+        align[:n_old, :, :w] = torch.where(earlier[:, :, None], carried.align[:, :, :w], align[:n_old, :, :w])
     done = torch.where(reached == 2, torch.zeros_like(n_frames), n_frames)
     post = self.postnet(mel, done)
-    return mel, post, gate, align, n_frames, reached, slots, memory, pm, all_lens
+    # one copy to the host for the three small per-utterance arrays (the decoder has finished: its call waited for it)
+    host = torch.stack([n_frames, reached.to(torch.int32), slots]).cpu().tolist()
+    n_frames_l, reached_l, slots_l = host
+    left = [b for b in range(B) if reached_l[b] == 2]
+    carried_out = None
+    if left:
+      idx = torch.tensor(left, dtype=torch.int64, device=self.device)
+      carried_out = CarriedRows(slots=[slots_l[b] for b in left], n_frames=[n_frames_l[b] for b in left],
+                                lengths=[all_lens[b] for b in left], rows=left,
+                                memory=memory.index_select(0, idx), processed_memory=pm.index_select(0, idx),
+                                mel=mel.index_select(0, idx), gate=gate.index_select(0, idx),
+                                align=None if align is None else align.index_select(0, idx))
+    return mel, post, gate, align, n_frames_l, reached_l, carried_out
 
   def inference_batch(self, symbols: torch.Tensor, stresses: Optional[torch.Tensor], tones: Optional[torch.Tensor],
                       durations: Optional[torch.Tensor], speakers: Optional[torch.Tensor],

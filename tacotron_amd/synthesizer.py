@@ -267,7 +267,7 @@ class Synthesizer:
   def launch_batch(self, lines: Sequence[Sequence[str]], speaker: Optional[str], max_decoder_steps: int = 3000,
                    seed: int = 0, include_stats: bool = False, keep_on_device: bool = False,
                    prepared: Optional[List[_Prepared]] = None, tags: Optional[Sequence[object]] = None,
-                   carry: Optional[List["_Unfinished"]] = None, leave_unfinished: bool = False) -> "_PendingBatch":
+                   carry: Optional["_Carry"] = None, leave_unfinished: bool = False) -> "_PendingBatch":
     """The device half of ``infer_batch``: encoder, decoder (the call returns when the decoder has finished), postnet
     and the copies to the host are enqueued, the copies are NOT waited for.  ``finish_batch`` waits for them and cuts
     the batch into per-line results - a caller with many batches runs it on another thread while this thread launches
@@ -277,12 +277,13 @@ class Synthesizer:
     lines still running are in ``pending.unfinished`` and go into the next launch as its ``carry``, where they continue
     from their next frame (bit for bit as if never interrupted).  ``tags`` name the lines (default: their index);
     ``pending.finished_tags`` are those of the results ``finish_batch`` returns."""
-    carry = list(carry or [])
+    old_preps = list(carry.preps) if carry else []
+    old_tags = list(carry.tags) if carry else []
     new_preps = list(prepared if prepared is not None else self.prepare_batch(lines, speaker))
-    preps = [u.prep for u in carry] + new_preps
-    all_tags = [u.tag for u in carry] + list(tags if tags is not None else range(len(new_preps)))
+    preps = old_preps + new_preps
+    all_tags = old_tags + list(tags if tags is not None else range(len(new_preps)))
     lens = [len(p.ids["symbols"]) for p in preps]
-    new_lens = lens[len(carry):]
+    new_lens = lens[len(old_preps):]
     T = max(new_lens) if new_lens else 0
     init_global_seeds(seed)
 
@@ -299,26 +300,23 @@ class Synthesizer:
       speakers = torch.full((len(new_preps), T), new_preps[0].speaker_id, dtype=torch.int64, device=self.device)
     lens_t = torch.tensor(new_lens, dtype=torch.int32, device=self.device) if new_preps else None
     start = time.perf_counter()
-    slots = memory = pm = None
+    left = None
     if carry or leave_unfinished:
-      mel, post, gate, align, n_frames, reached, slots, memory, pm, _ = self.model.inference_batch_resumable(
+      mel, post, gate, align, n_frames, reached, left = self.model.inference_batch_resumable(
         padded("symbols"), padded("stresses"), padded("tones"), padded("durations"), speakers, lens_t, max_decoder_steps,
-        [dict(slot=u.slot, n_frames=u.n_frames, length=len(u.prep.ids["symbols"]), memory=u.memory, processed_memory=u.processed_memory,
-              mel=u.mel, gate=u.gate, align=u.align) for u in carry], leave_unfinished, want_align=include_stats)
-      slots = slots.cpu().tolist()
+        carry.rows if carry else None, leave_unfinished, want_align=include_stats)
     else:
       mel, post, gate, align, n_frames, reached = self.model.inference_batch(
         padded("symbols"), padded("stresses"), padded("tones"), padded("durations"), speakers, lens_t,
         max_decoder_steps, want_align=include_stats)
-    # (the decoder has finished - its call waits for it -, so the frame counts are final)
-    n_frames = n_frames.cpu().tolist()
-    reached = reached.cpu().tolist()
+      # (the decoder has finished - its call waits for it -, so the frame counts are final)
+      n_frames = n_frames.cpu().tolist()
+      reached = reached.cpu().tolist()
     pending = _PendingBatch(self, preps, lens, n_frames, reached, include_stats, keep_on_device, start)
     pending.rows = [b for b in range(len(preps)) if reached[b] != 2]
     pending.finished_tags = [all_tags[b] for b in pending.rows]
-    pending.unfinished = [_Unfinished(all_tags[b], preps[b], slots[b], n_frames[b], mel[b], gate[b], None if align is None else align[b],
-                                      memory[b], pm[b])
-                          for b in range(len(preps)) if reached[b] == 2]
+    if left is not None:
+      pending.unfinished = _Carry([all_tags[b] for b in left.rows], [preps[b] for b in left.rows], left)
     if keep_on_device:
       pending.arrays = (post, mel, gate, align)
       return pending
@@ -361,18 +359,15 @@ class Synthesizer:
     return out
 
 
-@dataclass
-class _Unfinished:
-  """A line a launch left unfinished: what the next launch needs to take it up again."""
-  tag: object
-  prep: _Prepared
-  slot: int
-  n_frames: int
-  mel: torch.Tensor                      # [n_mel, T_cap] row of the launch that left it (frames so far)
-  gate: torch.Tensor                     # [T_cap]
-  align: Optional[torch.Tensor]          # [T_cap, T_in of that launch] or None
-  memory: torch.Tensor                   # the encoder's output for the line, [T_in of that launch, M] (not computed again)
-  processed_memory: torch.Tensor         # [T_in of that launch, A]
+class _Carry:
+  """The lines a launch left unfinished: their tags and prepared inputs, and what the model needs to take them up
+  again in the next launch (``tacotron_amd.model.CarriedRows``, one row per line, in this order)."""
+
+  def __init__(self, tags: List[object], preps: List[_Prepared], rows) -> None:
+    self.tags, self.preps, self.rows = tags, preps, rows
+
+  def __len__(self) -> int:
+    return len(self.tags)
 
 
 class _PendingBatch:
@@ -387,7 +382,7 @@ class _PendingBatch:
     self.keep = None
     self.rows: List[int] = list(range(len(preps)))      # rows whose utterances have finished
     self.finished_tags: List[object] = list(range(len(preps)))
-    self.unfinished: List["_Unfinished"] = []
+    self.unfinished: Optional["_Carry"] = None       # lines left to the next launch (None: every line has finished)
 
   def release(self) -> None:
     """Gives the batch's staging set back (its result arrays must not be used afterwards)."""

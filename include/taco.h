@@ -176,8 +176,7 @@ int taco_decode(taco_handle h, const float* memory, const float* processed_memor
  * launch ends as soon as a slot has no successor instead, and the utterances still running keep their state inside the
  * handle.  For each of them n_frames[b] = the frames it has so far, reached_max[b] = 2 and slot_out[b] = its slot; the
  * frames are in mel / gate / align as far as they go.  The caller puts those utterances into its next call - the same
- * memory / processed_memory rows again (the very values: taco_encode's output for a line may differ in the last bits
- * from one batch to the next), at any index - with resume_slot[b] = that slot: they go on from their next
+ * memory / processed_memory rows again, at any index - with resume_slot[b] = that slot: they go on from their next
  * frame, writing columns n_frames[b].. of the NEW call's outputs (the caller copies the earlier columns over), bit for
  * bit as if they had never been interrupted.  The handle keeps ONE such state: every left utterance must be resumed by
  * the next lockstep call on the handle (or abandoned by not naming its slot), with the same masks and limits.

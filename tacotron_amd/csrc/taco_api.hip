@@ -30,7 +30,7 @@ extern "C" const char* taco_version(void) { return "taco-hip 0.1 gfx950"; }
 #define TACO_NOALLOC_HALF (512u * (unsigned)TACO_NOALLOC_COLS)
 // ... followed by the convolutions' partial-tile workspace (4 MiB + one counter per tile; the counters start as the
 // zeros a code object's arrays are loaded with, and every launch leaves them zero)
-static __device__ __align__(256) float taco_noalloc_scratch[2u * TACO_NOALLOC_HALF + taco_conv_split_floats()];
+static __device__ __align__(256) float taco_noalloc_scratch[2u * TACO_NOALLOC_HALF + taco_conv_split_floats(TACO_CONV_SPLIT_CAP_BUILTIN)];
 static float* g_noalloc_ptr[64] = {nullptr};
 
 namespace {
@@ -270,13 +270,13 @@ extern "C" int taco_create(const taco_dims* dims, const taco_weights* weights, i
     h->wf_b = cur; cur += ((size_t)d.P + 63) / 64 * 64;
     float* wp_h = cur; cur += ((size_t)d.n_mel * d.R_d + 63) / 64 * 64;
     rc = taco_launch_slice_cols(hw.proj_w, d.R_d + d.M, 0, d.n_mel, d.R_d, wp_h, 0);
-    if (rc == TACO_OK) rc = taco_launch_conv(wp_h, h->wf_h, hw.prenet_w1, nullptr, nullptr, nullptr, nullptr, nullptr, 1, d.n_mel, d.P, 1, d.R_d, 0, 0, nullptr, h->n_cu, 0);
-    if (rc == TACO_OK) rc = taco_launch_conv(hw.proj_b, h->wf_b, hw.prenet_w1, nullptr, nullptr, nullptr, nullptr, nullptr, 1, d.n_mel, d.P, 1, 1, 0, 0, nullptr, h->n_cu, 0);
+    if (rc == TACO_OK) rc = taco_launch_conv(wp_h, h->wf_h, hw.prenet_w1, nullptr, nullptr, nullptr, nullptr, nullptr, 1, d.n_mel, d.P, 1, d.R_d, 0, 0, nullptr, 0, h->n_cu, 0);
+    if (rc == TACO_OK) rc = taco_launch_conv(hw.proj_b, h->wf_b, hw.prenet_w1, nullptr, nullptr, nullptr, nullptr, nullptr, 1, d.n_mel, d.P, 1, 1, 0, 0, nullptr, 0, h->n_cu, 0);
     // wf_c = W1 [P][n_mel] * Wp_c [n_mel][M]: the same fold for the projection's context columns (lockstep decoder)
     h->wf_c = cur; cur += ((size_t)d.P * d.M + 63) / 64 * 64;
     float* wp_c = cur; cur += ((size_t)d.n_mel * d.M + 63) / 64 * 64;
     if (rc == TACO_OK) rc = taco_launch_slice_cols(hw.proj_w, d.R_d + d.M, d.R_d, d.n_mel, d.M, wp_c, 0);
-    if (rc == TACO_OK) rc = taco_launch_conv(wp_c, h->wf_c, hw.prenet_w1, nullptr, nullptr, nullptr, nullptr, nullptr, 1, d.n_mel, d.P, 1, d.M, 0, 0, nullptr, h->n_cu, 0);
+    if (rc == TACO_OK) rc = taco_launch_conv(wp_c, h->wf_c, hw.prenet_w1, nullptr, nullptr, nullptr, nullptr, nullptr, 1, d.n_mel, d.P, 1, d.M, 0, 0, nullptr, 0, h->n_cu, 0);
     if (rc != TACO_OK) { taco_destroy(h); return rc; }
   }
   TACO_CREATE_HIP(hipGetLastError());
@@ -296,8 +296,8 @@ extern "C" int taco_create(const taco_dims* dims, const taco_weights* weights, i
     if (rc == TACO_OK) rc = taco_decoder_batch_pack(h);
     if (rc != TACO_OK) { taco_destroy(h); return rc; }
   }
-  TACO_CREATE_HIP(hipMalloc((void**)&h->conv_split, taco_conv_split_floats() * sizeof(float)));
-  TACO_CREATE_HIP(hipMemset(h->conv_split, 0, taco_conv_split_floats() * sizeof(float)));
+  TACO_CREATE_HIP(hipMalloc((void**)&h->conv_split, taco_conv_split_floats(TACO_CONV_SPLIT_CAP) * sizeof(float)));
+  TACO_CREATE_HIP(hipMemset(h->conv_split, 0, taco_conv_split_floats(TACO_CONV_SPLIT_CAP) * sizeof(float)));
   h->enc_gran_count = taco_enc_lstm_granules(h->n_cu);
   TACO_CREATE_HIP(hipMalloc((void**)&h->enc_gran, h->enc_gran_count * sizeof(taco_granule)));
   h->dec_ctl_cap = 64;
@@ -378,13 +378,13 @@ extern "C" int taco_encode(taco_handle h, const int64_t* const* ids, const int64
   int cur = 0;
   for (int l = 0; l < d.n_enc; ++l) {
     rc = taco_launch_conv(h->ws_act[cur], h->ws_act[cur ^ 1], h->w.enc_conv_w[l], h->w.enc_conv_b[l], h->enc_alpha[l],
-                          h->enc_beta[l], nullptr, lens, B, d.E, d.E, d.k_enc, T_in, /*relu*/ 1, 0, h->conv_split, h->n_cu, s);
+                          h->enc_beta[l], nullptr, lens, B, d.E, d.E, d.k_enc, T_in, /*relu*/ 1, 0, h->conv_split, TACO_CONV_SPLIT_CAP, h->n_cu, s);
     if (rc != TACO_OK) return rc;
     cur ^= 1;
   }
   // LSTM input projections of both directions for every position: a kernel-size-1 convolution
   rc = taco_launch_conv(h->ws_act[cur], h->ws_gx, h->lstm_w_ih_cat, h->lstm_bias_sum, nullptr, nullptr, nullptr, lens,
-                        B, d.E, 8 * d.H_e, 1, T_in, 0, 0, h->conv_split, h->n_cu, s);
+                        B, d.E, 8 * d.H_e, 1, T_in, 0, 0, h->conv_split, TACO_CONV_SPLIT_CAP, h->n_cu, s);
   if (rc != TACO_OK) return rc;
   TACO_HIP(hipMemsetAsync(memory, 0, sizeof(float) * (size_t)B * T_in * d.M, s));
   rc = taco_launch_enc_lstm(h, h->ws_gx, lens, B, T_in, memory, s);
@@ -556,7 +556,7 @@ extern "C" int taco_postnet(taco_handle h, const float* mel, const int32_t* n_fr
     float* dst = last ? out : h->ws_act[cur];
     rc = taco_launch_conv(cur_in, dst, h->w.post_conv_w[l], h->w.post_conv_b[l], h->post_alpha[l], h->post_beta[l],
                           last ? mel : nullptr, n_frames, B, c_in, c_out, d.k_post, T_cap, last ? 0 : /*tanh*/ 2, 0, h->conv_split,
-                          h->n_cu, s);
+                          TACO_CONV_SPLIT_CAP, h->n_cu, s);
     if (rc != TACO_OK) return rc;
     cur_in = dst;
     cur ^= 1;
@@ -592,7 +592,7 @@ extern "C" int taco_postnet_noalloc(taco_handle h, const float* mel, const int32
     // scratch's previous contents is ever read
     const int rc = taco_launch_conv(cur_in, dst, h->w.post_conv_w[l], h->w.post_conv_b[l], h->post_alpha[l], h->post_beta[l],
                                     last ? mel : nullptr, n_frames, B, c_in, c_out, d.k_post, T_cap, last ? 0 : /*tanh*/ 2, 0, split_ws,
-                                    h->n_cu, s);
+                                    TACO_CONV_SPLIT_CAP_BUILTIN, h->n_cu, s);
     if (rc != TACO_OK) return rc;
     cur_in = dst;
     cur ^= 1;

@@ -918,13 +918,13 @@ int taco_launch_decoder(taco_handle h, const float* memory, const float* pm, int
   // folded context weights of this utterance: G = ctx_w_cat [rows][M] * memory^T [M][T_in], run as a
   // kernel-size-1 convolution over the position-major memory (columns >= len come out as zero)
   const int rc = taco_launch_conv(memory, h->ws_G, h->ctx_w_cat, nullptr, nullptr, nullptr, nullptr,
-                                  lens ? lens + b : nullptr, 1, d.M, h->ctx_rows, 1, T_in, 0, /*in_time_major*/ 1, h->conv_split, h->n_cu, s);
+                                  lens ? lens + b : nullptr, 1, d.M, h->ctx_rows, 1, T_in, 0, /*in_time_major*/ 1, h->conv_split, TACO_CONV_SPLIT_CAP, h->n_cu, s);
   if (rc != TACO_OK) return rc;
   // ... and prenet layer 1 applied to the projection's folded rows: [P][T_in] = W1 [P][n_mel] * G_proj [n_mel][T_in]
   {
     float* g_proj = h->ws_G + (size_t)(4 * d.R_a + 4 * d.R_d) * T_in;
     const int rc2 = taco_launch_conv(g_proj, h->ws_G + (size_t)h->ctx_rows * T_in, h->w.prenet_w1, nullptr, nullptr, nullptr,
-                                     nullptr, lens ? lens + b : nullptr, 1, d.n_mel, d.P, 1, T_in, 0, 0, h->conv_split, h->n_cu, s);
+                                     nullptr, lens ? lens + b : nullptr, 1, d.n_mel, d.P, 1, T_in, 0, 0, h->conv_split, TACO_CONV_SPLIT_CAP, h->n_cu, s);
     if (rc2 != TACO_OK) return rc2;
   }
 

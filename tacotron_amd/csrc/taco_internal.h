@@ -157,12 +157,19 @@ int taco_launch_embed(taco_handle h, const int64_t* const* ids_dev, const int32_
 // columns >= lens[b] are written as zero.
 int taco_launch_conv(const float* in, float* out, const float* w, const float* bias, const float* alpha,
                      const float* beta, const float* residual, const int32_t* lens, int B, int c_in,
-                     int c_out, int k, int T, int act, int layout, float* split_ws, int n_cu, hipStream_t s);
-// split_ws: workspace of taco_conv_split_floats() floats (partial tiles, then one counter per tile; the counters must
-// be zero when the first launch uses them and every launch leaves them zero), or NULL = every tile by one workgroup.
-// Launches that share a workspace must not overlap.
-constexpr int TACO_CONV_SPLIT_SLABS = 512;                   // partial tiles of 32 x 64 floats
-constexpr size_t taco_conv_split_floats() { return (size_t)TACO_CONV_SPLIT_SLABS * 2048 + TACO_CONV_SPLIT_SLABS; }
+                     int c_out, int k, int T, int act, int layout, float* split_ws, int split_cap, int n_cu, hipStream_t s);
+// A tile's sum over the input channels is made of UNITS of TACO_CONV_UNIT_SLABS slabs: the products of a unit form one
+// accumulation chain, the units' sums are added in order - whether one workgroup runs all units of a tile or, in launches
+// with few tiles, every unit has a workgroup of its own.  So a result does not depend on how large its launch was
+// (an utterance's encoder and postnet outputs are bit-identical whatever batch it is in).
+// split_ws: workspace of taco_conv_split_floats(split_cap) floats (split_cap workgroups' partial tiles, then one counter
+// per tile; the counters must be zero when the first launch uses them and every launch leaves them zero), or NULL =
+// every tile by one workgroup.  Launches that share a workspace must not overlap.
+constexpr int TACO_CONV_UNIT_SLABS = 4;
+constexpr int TACO_CONV_PARTIAL = 4 * 16 * 64;               // floats a workgroup leaves: four waves' 32 x 32 accumulators
+constexpr int TACO_CONV_SPLIT_CAP = 512;                     // workgroup partials in a handle's workspace (8 MiB)
+constexpr int TACO_CONV_SPLIT_CAP_BUILTIN = 256;             // ... in the built-in scratch of taco_postnet_noalloc (4 MiB)
+constexpr size_t taco_conv_split_floats(int cap) { return (size_t)cap * TACO_CONV_PARTIAL + (size_t)cap; }
 int taco_conv_prepare();
 int taco_launch_enc_lstm(taco_handle h, const float* gx, const int32_t* lens, int B, int T, float* memory,
                          hipStream_t s);

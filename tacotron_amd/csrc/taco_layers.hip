@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void taco_conv_kernel(const float* __restrict_
                                                         const float* __restrict__ alpha, const float* __restrict__ beta,
                                                         const float* __restrict__ residual, const int32_t* lens,
                                                         int c_in, int c_out, int T, int act, int layout,
-                                                        int split, float* split_ws) {
+                                                        int split, float* split_ws, int split_cap) {
   constexpr bool in_time_major = IN_TM;          // input is [T][C] instead of [C][T]
   const bool out_time_major = layout & 2;        // output likewise
   constexpr int CI = taco_conv_ci(KS);         // input channels per slab
@@ -103,8 +103,8 @@ __global__ __launch_bounds__(256) void taco_conv_kernel(const float* __restrict_
   const int thalf = wave & 1, khalf = wave >> 1;
   const int i = lane & 31, h = lane >> 5;
   const int b = blockIdx.z;
-  // split > 1: `split` consecutive workgroups share an output tile, each with its own range of slabs (see the end of
-  // the slab loop for how their partial tiles meet)
+  // split > 1: `split` consecutive workgroups share an output tile, each with one unit of slabs (see the end of the
+  // slab loop for how their partial tiles meet)
   // layout & 4: the grid is (channel blocks, column tiles, utterances) instead of (column tiles x split, channel blocks,
   // utterances).  Workgroups go to the eight XCDs round-robin in launch order, so what runs fastest through the grid decides
   // what an XCD gets: with the column tiles there and 16 tiles of which a ragged batch fills only the first few, XCD 0 (tiles
@@ -117,9 +117,9 @@ __global__ __launch_bounds__(256) void taco_conv_kernel(const float* __restrict_
   const int co0 = (by_block ? blockIdx.x : blockIdx.y) * CV_CO;
   const int len = lens ? min(lens[b], T) : T;      // (a length beyond the buffers' T columns is read as T)
   const float* in_b = in + (size_t)b * c_in * T;
-  taco_f32x16 acc;
+  taco_f32x16 acc, tot;       // the running unit's accumulation chain; the sum of the units before it
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  for (int r = 0; r < 16; ++r) acc[r] = tot[r] = 0.0f;
 
   if (t0 < len) {
     // Staging map.  Weights: thread = (row tid >> 3, segment tid & 7), row = output channel, the thread takes NW
@@ -190,8 +190,9 @@ __global__ __launch_bounds__(256) void taco_conv_kernel(const float* __restrict_
       }
     };
     const int n_slabs_all = (c_in + CI - 1) / CI;
-    const int sl0 = ksl * n_slabs_all / split;                     // my slabs: sl0 .. sl0 + n_slabs - 1 (at least one)
-    const int n_slabs = (ksl + 1) * n_slabs_all / split - sl0;
+    // my slabs: sl0 .. sl0 + n_slabs - 1 (at least one) - all of them, or unit ksl when every unit has its own workgroup
+    const int sl0 = split > 1 ? ksl * TACO_CONV_UNIT_SLABS : 0;
+    const int n_slabs = split > 1 ? min(TACO_CONV_UNIT_SLABS, n_slabs_all - sl0) : n_slabs_all;
     // One slab: multiply slab s (LDS buffer s & 1), fetch slab s + 2 into `fetch`, park slab s + 1 (`park`, fetched one
     // slab ago) in the other LDS buffer.  A wave's products form one dependent chain (a product issues when the one
     // before has left the matrix core, 64 cycles), and a wave issues in order: whatever stands between two products
@@ -236,12 +237,66 @@ __global__ __launch_bounds__(256) void taco_conv_kernel(const float* __restrict_
     // (Both slabs of a pair unconditionally inside the loop, the odd one behind it: with `if (s + 1 < n_slabs)` around
     // the second, the compiler sees a path from the first slab straight back to the loop's top on which the first
     // slab's loads are still in flight, and drains every load at the top of each pair.)
+    static_assert(TACO_CONV_UNIT_SLABS % 2 == 0, "units are whole pairs of slabs");
     int s = 0;
     for (; s + 1 < n_slabs; s += 2) {
       slab(s, pwA, pxA, pwB, pxB);
       slab(s + 1, pwB, pxB, pwA, pxA);
+      if (((s + 2) & (TACO_CONV_UNIT_SLABS - 1)) == 0) {      // a unit is complete: its chain ends here
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { tot[r] += acc[r]; acc[r] = 0.0f; }
+      }
     }
     if (s < n_slabs) slab(s, pwA, pxA, pwB, pxB);
+    // (a last unit of fewer slabs; after a whole number of units this adds zeros)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = tot[r] + acc[r];
+    if (split > 1) {
+      // Every workgroup of the tile leaves its unit's four accumulator tiles in global memory (write-through 16-byte
+      // stores, so no release fence is needed) and draws a ticket from the tile's counter; the one that draws the last
+      // ticket adds all units from memory - its own included, in unit order, every wave its own tile: the very sums a
+      // single workgroup running all units would have made - and goes on.  It also puts the counter back to zero for the
+      // next launch that uses it.  Partial of unit k of tile n: floats [(n * split + k) * 4096 ..) as
+      // [wave][register quad][lane][4].
+      const unsigned tiles_t = gridDim.x / (unsigned)split;
+      const unsigned tile = ((unsigned)b * gridDim.y + blockIdx.y) * tiles_t + (unsigned)tile_t;
+      const unsigned n_part = gridDim.z * gridDim.y * tiles_t * (unsigned)split;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)split_ws, 0, (int)(n_part * (TACO_CONV_PARTIAL * 4u)), 0x00020000);
+      unsigned* counters = reinterpret_cast<unsigned*>(split_ws + (size_t)split_cap * TACO_CONV_PARTIAL);
+      const unsigned lane_off = ((unsigned)wave * 4u * 64u + (unsigned)lane) * 16u;
+      {
+        const unsigned at = (tile * (unsigned)split + (unsigned)ksl) * (TACO_CONV_PARTIAL * 4u) + lane_off;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const taco_u4 v = {__float_as_uint(acc[4 * q]), __float_as_uint(acc[4 * q + 1]), __float_as_uint(acc[4 * q + 2]),
+                             __float_as_uint(acc[4 * q + 3])};
+          __builtin_amdgcn_raw_buffer_store_b128(v, rs, at + (unsigned)q * 1024u, 0, 16 /* sc1: write-through */);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave's stores have been acknowledged
+      __syncthreads();
+      unsigned* ticket_lds = reinterpret_cast<unsigned*>(conv_lds);      // the input buffers are no longer in use
+      if (tid == 0) *ticket_lds = __hip_atomic_fetch_add(counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      if (*ticket_lds != (unsigned)split - 1u) return;
+      if (tid == 0) __hip_atomic_store(counters + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+      for (int k = 0; k < split; ++k) {
+        const unsigned at = (tile * (unsigned)split + (unsigned)k) * (TACO_CONV_PARTIAL * 4u) + lane_off;
+        taco_u4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, at + (unsigned)q * 1024u, 0, 16 /* sc1: past this CU's L1 */);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          acc[4 * q] += __uint_as_float(v[q].x);
+          acc[4 * q + 1] += __uint_as_float(v[q].y);
+          acc[4 * q + 2] += __uint_as_float(v[q].z);
+          acc[4 * q + 3] += __uint_as_float(v[q].w);
+        }
+      }
+      __syncthreads();                                      // (the ticket word lies in the buffers used next)
+    }
     // add the two channel halves: waves 2, 3 hand their tiles to waves 0, 1 through LDS
     float* red = &ws[0][0][0];     // 2 x 16 x 64 floats fit the weight buffers
     if (khalf == 1) {
@@ -252,53 +307,6 @@ __global__ __launch_bounds__(256) void taco_conv_kernel(const float* __restrict_
     if (khalf == 0) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] += red[(thalf * 16 + r) * 64 + lane];
-    }
-    if (split > 1) {
-      // The workgroups of a tile leave their partial tiles in global memory (write-through 16-byte stores, so no release
-      // fence is needed), draw a ticket from the tile's counter, and the one that draws the last ticket adds all the
-      // partial tiles - its own included, from memory, in slab order, so the sum does not depend on who came last - and
-      // goes on to the epilogue.  It also puts the counter back to zero for the next launch that uses it.
-      // Partial tile of slice k of tile n: floats [(n * split + k) * 2048 ..), as [column half][register quad][lane][4].
-      const unsigned tiles_t = gridDim.x / (unsigned)split;
-      const unsigned tile = ((unsigned)b * gridDim.y + blockIdx.y) * tiles_t + (unsigned)tile_t;
-      const unsigned n_part = gridDim.z * gridDim.y * tiles_t * (unsigned)split;
-      typedef unsigned taco_u4 __attribute__((ext_vector_type(4)));
-      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)split_ws, 0, (int)(n_part * (CV_CO * CV_TT * 4u)), 0x00020000);
-      unsigned* counters = reinterpret_cast<unsigned*>(split_ws + (size_t)TACO_CONV_SPLIT_SLABS * (CV_CO * CV_TT));
-      const unsigned lane_off = ((unsigned)thalf * 4u * 64u + (unsigned)lane) * 16u;
-      if (khalf == 0) {
-        const unsigned at = (tile * (unsigned)split + (unsigned)ksl) * (CV_CO * CV_TT * 4u) + lane_off;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const taco_u4 v = {__float_as_uint(acc[4 * q]), __float_as_uint(acc[4 * q + 1]), __float_as_uint(acc[4 * q + 2]),
-                             __float_as_uint(acc[4 * q + 3])};
-          __builtin_amdgcn_raw_buffer_store_b128(v, rs, at + (unsigned)q * 1024u, 0, 16 /* sc1: write-through */);
-        }
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave's stores have been acknowledged
-      __syncthreads();
-      unsigned* ticket_lds = reinterpret_cast<unsigned*>(conv_lds);      // the input buffers are no longer in use
-      if (tid == 0) *ticket_lds = __hip_atomic_fetch_add(counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __syncthreads();
-      if (*ticket_lds != (unsigned)split - 1u) return;
-      if (tid == 0) __hip_atomic_store(counters + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (khalf == 0) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-        for (int k = 0; k < split; ++k) {
-          const unsigned at = (tile * (unsigned)split + (unsigned)k) * (CV_CO * CV_TT * 4u) + lane_off;
-          taco_u4 v[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, at + (unsigned)q * 1024u, 0, 16 /* sc1: past this CU's L1 */);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            acc[4 * q] += __uint_as_float(v[q].x);
-            acc[4 * q + 1] += __uint_as_float(v[q].y);
-            acc[4 * q + 2] += __uint_as_float(v[q].z);
-            acc[4 * q + 3] += __uint_as_float(v[q].w);
-          }
-        }
-      }
     }
   }
   if (khalf != 0) return;
@@ -555,24 +563,24 @@ int taco_conv_prepare() {
 // (102 symbols: 34 tiles -> 7 workgroups each, 37 -> 20 us per layer) and the postnet (250 frames: 171 -> 95 us for
 // the five layers; 1000 frames: the 80-channel last layer 41 -> 23 us); filling the device twice or cutting the
 // 256-tile layers in two gained nothing: two workgroups on a CU take as long as one with twice the slabs.
-static int taco_conv_split_factor(int base_tiles, int n_slabs, int n_cu) {
-  int split = n_cu / (base_tiles > 0 ? base_tiles : 1);
-  if (split > 8) split = 8;
-  if (split > n_slabs / 2) split = n_slabs / 2;
-  while (split > 1 && (size_t)base_tiles * split > (size_t)TACO_CONV_SPLIT_SLABS) --split;
-  if (base_tiles > TACO_CONV_SPLIT_SLABS) split = 1;
-  return split < 1 ? 1 : split;
+static int taco_conv_split_factor(int base_tiles, int n_slabs, int n_cu, int split_cap) {
+  // all or nothing: every unit of slabs gets a workgroup of its own, or one workgroup runs them all (either way the
+  // units' sums are added in the same order, so the choice never shows in the result)
+  const int units = (n_slabs + TACO_CONV_UNIT_SLABS - 1) / TACO_CONV_UNIT_SLABS;
+  if (units < 2 || base_tiles < 1) return 1;
+  const size_t wgs = (size_t)base_tiles * units;
+  return (wgs <= (size_t)split_cap && wgs <= (size_t)n_cu + (size_t)n_cu / 2) ? units : 1;
 }
 
 int taco_launch_conv(const float* in, float* out, const float* w, const float* bias, const float* alpha,
                      const float* beta, const float* residual, const int32_t* lens, int B, int c_in,
-                     int c_out, int k, int T, int act, int layout, float* split_ws, int n_cu, hipStream_t s) {
+                     int c_out, int k, int T, int act, int layout, float* split_ws, int split_cap, int n_cu, hipStream_t s) {
   // the kernel addresses one utterance's input and the weights through 32-bit buffer offsets
   if ((uint64_t)c_in * (uint64_t)T * 4u >= 0xffffffffull || (uint64_t)c_out * (uint64_t)c_in * (uint64_t)k * 4u >= 0xffffffffull)
     TACO_FAIL(TACO_EINVAL, "convolution operand of %d x %d columns / %d x %d x %d weights exceeds 4 GiB", c_in, T, c_out, c_in, k);
   const int tiles_t = (T + CV_TT - 1) / CV_TT, tiles_co = (c_out + CV_CO - 1) / CV_CO;
   const int ci = taco_conv_ci(k);
-  const int split = split_ws ? taco_conv_split_factor(tiles_t * tiles_co * B, (c_in + ci - 1) / ci, n_cu) : 1;
+  const int split = split_ws ? taco_conv_split_factor(tiles_t * tiles_co * B, (c_in + ci - 1) / ci, n_cu, split_cap) : 1;
   dim3 grid(tiles_t * split, tiles_co, B);
   if (split == 1 && tiles_t <= 65535) {          // (a grid's y extent ends at 65535)
     grid = dim3(tiles_co, tiles_t, B);
@@ -583,10 +591,10 @@ int taco_launch_conv(const float* in, float* out, const float* w, const float* b
   case KS:                                                                                          \
     if (layout & 1)                                                                                 \
       hipLaunchKernelGGL((taco_conv_kernel<KS, true>), grid, dim3(256), taco_conv_lds_bytes(KS), s, in, out, w, bias, alpha, beta, \
-                         residual, lens, c_in, c_out, T, act, layout, split, split_ws);       \
+                         residual, lens, c_in, c_out, T, act, layout, split, split_ws, split_cap); \
     else                                                                                            \
     hipLaunchKernelGGL((taco_conv_kernel<KS, false>), grid, dim3(256), taco_conv_lds_bytes(KS), s, in, out, w, bias, alpha, beta,  \
-                       residual, lens, c_in, c_out, T, act, layout, split, split_ws);             \
+                       residual, lens, c_in, c_out, T, act, layout, split, split_ws, split_cap); \
     break;
     TACO_CONV_CASE(1)
     TACO_CONV_CASE(3)
@@ -653,5 +661,5 @@ int taco_launch_memory_tail(taco_handle h, const int64_t* speakers, const int32_
   TACO_HIP(hipGetLastError());
   // processed_memory = memory_layer(memory): a kernel-size-1 convolution, position-major in and out
   return taco_launch_conv(memory, pm, h->w.memory_w, nullptr, nullptr, nullptr, nullptr, lens, B, d.M, d.A, 1, T, 0,
-                          /*position-major in and out*/ 3, h->conv_split, h->n_cu, s);
+                          /*position-major in and out*/ 3, h->conv_split, TACO_CONV_SPLIT_CAP, h->n_cu, s);
 }

@@ -258,8 +258,7 @@ class Tacotron2:
     mostly empty decoder slots: with ``leave_unfinished`` the decoder stops as soon as a slot has no successor; the
     utterances still running come back with ``reached == 2``, their frames so far, and - as ``carried_out`` - what the
     next call needs to take them up again (``CarriedRows``: their slots, frame counts, lengths, and their rows of the
-    encoder's output and of mel / gate / alignments; the encoder is not run again for them: its output for a line may
-    differ in the last bits from one batch to the next).  Passed as the next call's ``carried`` they are the first rows
+    encoder's output and of mel / gate / alignments; the encoder is not run again for them).  Passed as the next call's ``carried`` they are the first rows
     of that call's results, go on from their next frame - bit for bit as if never interrupted - with their earlier
     columns in place; the id tensors (``symbols`` ... ``lens``) hold the NEW utterances only (``symbols`` None: there are
     none).  The postnet skips the rows left unfinished.  ``max_decoder_steps`` must be positive.

@@ -19,7 +19,7 @@ m = Tacotron2(hp, **abi.mapping_counts(ckpt, hp)); m.load_state_dict(ckpt["model
 d = lambda a: None if a is None else torch.from_numpy(a).to("cuda:0")
 masks = prenet_keep_masks(1111, frames, m.dims.P).to("cuda:0")
 bad = 0
-for T_in in (1, 30, 102, 256, 300, 512):
+for T_in in (1, 30, 102, 256, 300, 512, 700, 1024):
   ids = scenarios.random_ids(ckpt, [T_in], seed=T_in)
   chans = [d(ids[k]) for k in ("symbols", "stresses", "tones", "durations") if ids[k] is not None]
   mem, pm = m.encode(chans, d(ids["speakers"]), None)
@@ -85,5 +85,34 @@ for B, steps in ((64, 400), (17, 150), (200, 250)):
   torch.cuda.synchronize()
   print(f"lockstep B={B}: {reps} launches (forwards / backwards), {int(first[3].sum())} frames each, identical={bad == 0} "
         f"({time.perf_counter() - t0:.1f} s)", flush=True)
+  # the same batch in three calls, each but the last leaving its running utterances to the next (taco_decode_resumable):
+  # every utterance must come out bit for bit as in the one-call launches above
+  t0 = time.perf_counter()
+  thirds = [list(range(0, B // 3)), list(range(B // 3, 2 * B // 3)), list(range(2 * B // 3, B))]
+  for i in range(max(2, reps // 4)):
+    carried = []          # (utterance, slot, frames so far, mel row, gate row, align row)
+    done = 0
+    for c, new in enumerate(thirds):
+      rows = [x[0] for x in carried] + new
+      idx = torch.tensor(rows, device="cuda:0")
+      resume = torch.tensor([x[1] for x in carried] + [-1] * len(new), dtype=torch.int32, device="cuda:0")
+      mel, gt, align, nf, reached, slots = m.decode(mem[idx].contiguous(), pm[idx].contiguous(), ln[idx].contiguous(), mk, steps,
+                                                    resume_slots=resume if carried else None, leave_unfinished=c + 1 < len(thirds))
+      for b, x in enumerate(carried):
+        mel[b, :, :x[2]] = x[3][:, :x[2]]; gt[b, :x[2]] = x[4][:x[2]]; align[b, :x[2]] = x[5][:x[2]]
+      nf_h, re_h, sl_h = nf.cpu().tolist(), reached.cpu().tolist(), slots.cpu().tolist()
+      carried = []
+      for b, u in enumerate(rows):
+        if re_h[b] == 2:
+          carried.append((u, sl_h[b], nf_h[b], mel[b].clone(), gt[b].clone(), align[b].clone()))
+          continue
+        done += 1
+        if not (nf_h[b] == int(first[3][u]) and torch.equal(mel[b], first[0][u]) and torch.equal(gt[b], first[1][u])
+                and torch.equal(align[b], first[2][u])):
+          bad += 1
+          print(f"lockstep B={B} in three calls, pass {i}: utterance {u} differs from the one-call launch", flush=True)
+    assert done == B and not carried
+  torch.cuda.synchronize()
+  print(f"lockstep B={B}: in three calls with utterances left and resumed, identical={bad == 0} ({time.perf_counter() - t0:.1f} s)", flush=True)
 print("soak", "FAILED" if bad else "ok")
 sys.exit(1 if bad else 0)

@@ -569,7 +569,9 @@ static int taco_conv_split_factor(int base_tiles, int n_slabs, int n_cu, int spl
   const int units = (n_slabs + TACO_CONV_UNIT_SLABS - 1) / TACO_CONV_UNIT_SLABS;
   if (units < 2 || base_tiles < 1) return 1;
   const size_t wgs = (size_t)base_tiles * units;
-  return (wgs <= (size_t)split_cap && wgs <= (size_t)n_cu + (size_t)n_cu / 2) ? units : 1;
+  // up to two workgroups per CU (what a CU's LDS holds at once): postnet at 400 / 500 frames 137 -> 114 / 116 us; beyond
+  // that the split is slower than one workgroup per tile (600 frames: 155 against 143 us, 1000: 179 against 144)
+  return (wgs <= (size_t)split_cap && wgs <= 2 * (size_t)n_cu) ? units : 1;
 }
 
 int taco_launch_conv(const float* in, float* out, const float* w, const float* bias, const float* alpha,

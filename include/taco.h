@@ -180,7 +180,8 @@ int taco_decode(taco_handle h, const float* memory, const float* processed_memor
  * frame, writing columns n_frames[b].. of the NEW call's outputs (the caller copies the earlier columns over), bit for
  * bit as if they had never been interrupted.  The handle keeps ONE such state: every left utterance must be resumed by
  * the next lockstep call on the handle (or abandoned by not naming its slot), with the same masks and limits.
- *   resume_slot       device [B] int32 or NULL: slot to continue from, -1 = the utterance starts anew
+ *   resume_slot       device [B] int32 or NULL: slot to continue from, -1 = the utterance starts anew (a slot in which the
+ *                     handle's last lockstep launch left no utterance, or one named twice, is refused with TACO_EINVAL)
  *   leave_unfinished  0 = run every utterance to its end (what taco_decode does)
  *   slot_out          device [B] int32 (required unless both of the above are NULL / 0): -1, or the slot b was left in
  * Utterances too long for the lockstep decoder (over 224 symbols) are decoded to their end by the batch-1 kernel as in

@@ -496,6 +496,8 @@ extern "C" int taco_decode_resumable(taco_handle h, const float* memory, const f
       const int own = host_lens.empty() ? T_in : host_lens[b];
       if (sl >= TACO_BATCH_NB || ((taken >> sl) & 1u) || own > TACO_BT_TIN)
         TACO_FAIL(TACO_EINVAL, "taco_decode_resumable: resume_slot[%d] = %d (a slot is 0..%d, taken once, and its utterance fits the lockstep decoder)", b, sl, TACO_BATCH_NB - 1);
+      if (!((h->bat_left_slots >> sl) & 1u))
+        TACO_FAIL(TACO_EINVAL, "taco_decode_resumable: resume_slot[%d] = %d, but the handle's last lockstep launch left no utterance in that slot", b, sl);
       taken |= 1u << sl;
       resuming = true;
     }
@@ -512,6 +514,7 @@ extern "C" int taco_decode_resumable(taco_handle h, const float* memory, const f
   }
   int n_launches = 0;
   if (!fits.empty()) {
+    h->bat_left_slots = 0;      // whatever an earlier launch left is taken up now or gone (the launch overwrites the saved state)
     // one launch for all of them: the kernel itself walks the utterances in index order, skipping those beyond its capacity
     const int rc = taco_launch_decoder_batch(h, memory, processed_memory, T_in, lens, B, (int)fits.size(), n_launches, masks, T_cap,
                                              max_steps, gate_threshold, forced_mel, mel, gate, align, n_frames, reached_max,
@@ -532,8 +535,11 @@ extern "C" int taco_decode_resumable(taco_handle h, const float* memory, const f
   const int crc = taco_decoder_collect(h, n_launches, s);
   if (crc != TACO_OK) return crc;
   // a lockstep launch (always the call's first) that left utterances unfinished: keep the prenet output they were about to consume
-  if (leave_unfinished && !fits.empty() && h->dec_ctl_host[0].reached_max == 2u)
-    return taco_decoder_batch_keep_prenet_output(h, (int)h->dec_ctl_host[0].n_frames, s);
+  if (leave_unfinished && !fits.empty() && h->dec_ctl_host[0].reached_max == 2u) {
+    const int rc = taco_decoder_batch_keep_prenet_output(h, (int)h->dec_ctl_host[0].n_frames, s);
+    if (rc == TACO_OK) h->bat_left_slots = h->dec_ctl_host[0].left_slots;
+    return rc;
+  }
   return TACO_OK;
 }
 

@@ -1441,6 +1441,7 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
   if (j == 0 && tid == 0) {
     a.ctl->n_frames = (uint32_t)t;       // lockstep frames of the launch
     a.ctl->reached_max = left ? 2u : 0u;
+    a.ctl->left_slots = left ? (alive & 0xffffu) : 0u;      // the slots whose utterances were left (their state is in carry_*)
   }
 }
 

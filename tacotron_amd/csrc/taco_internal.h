@@ -88,7 +88,8 @@ struct taco_dec_ctl {      // device-visible control block (zeroed before every 
   uint32_t abort_info;     // vector id / frame of the failed wait
   uint32_t n_frames;       // frames produced
   uint32_t reached_max;
-  uint32_t pad_[12];
+  uint32_t left_slots;     // lockstep launch that left utterances unfinished: bit s = slot s holds one
+  uint32_t pad_[11];
 };
 
 struct taco_handle_s {
@@ -121,6 +122,7 @@ struct taco_handle_s {
   // workspaces (grow-only)
   float* ws_act[2];          // activation ping-pong [B][C_max][T]
   size_t ws_act_floats;
+  unsigned bat_left_slots;   // slots whose utterances the handle's last lockstep launch left unfinished (what a resuming call may name)
   float* conv_split;         // partial tiles and tile counters of the convolutions whose tiles are shared by several workgroups
   float* ws_gx;              // [B][2][4*H_e][T] LSTM input projections
   size_t ws_gx_floats;

@@ -78,3 +78,58 @@ def test_lines_decoded_across_calls_equal_one_uninterrupted_call(gate_table):
     assert torch.equal(got_mel[line][:, :n], want[0][line][:, :n]), line
     assert torch.equal(got_gate[line][:n], want[1][line][:n]), line
     assert torch.equal(got_align[line][:n, :], want[2][line][:n, :lens[line]]), line
+
+
+def test_only_slots_the_last_launch_left_can_be_resumed(gate_table):
+  """A resume request must name a slot in which the handle's LAST lockstep launch left an utterance: a slot nobody was
+  left in, a slot named twice, a slot number out of range, and a slot of the launch before the last are refused with
+  the library's argument error instead of continuing from whatever the saved state holds; the handle decodes on."""
+  from tacotron_amd._lib import TacoError, TacoTimeoutError
+  gate = gate_table["ljs"]
+  gm = gpu_model("ljs", gate)
+  ck = scenario_checkpoint("ljs", gate)
+  lens = np.random.RandomState(8).randint(20, 201, size=24).tolist()
+  max_steps = 120
+  masks = prenet_keep_masks(1111, max_steps, gm.dims.P)
+  mem, pm, ln = _encode(gm, ck, lens, seed=5)
+  minus = torch.full((24,), -1, dtype=torch.int32, device="cuda:0")
+
+  def refused(resume):
+    with pytest.raises(TacoError) as err:
+      gm.decode(mem, pm, ln, masks, max_steps, resume_slots=resume, leave_unfinished=False)
+    assert not isinstance(err.value, TacoTimeoutError) and "resume_slot" in str(err.value)
+
+  gm.decode(mem, pm, ln, masks, max_steps)                       # a plain call leaves nothing
+  one = minus.clone(); one[0] = 3
+  refused(one)
+  out = gm.decode(mem, pm, ln, masks, max_steps, leave_unfinished=True)
+  torch.cuda.synchronize()
+  left = [(b, s) for b, (r, s) in enumerate(zip(out[4].cpu().tolist(), out[5].cpu().tolist())) if r == 2]
+  assert left, "the calibrated stop leaves some of 24 lines running when the first slot frees"
+  free = sorted(set(range(16)) - {s for _, s in left})
+  if free:
+    bad = minus.clone(); bad[left[0][0]] = free[0]
+    refused(bad)                                                 # nobody was left in that slot
+  twice = minus.clone(); twice[left[0][0]] = left[0][1]; twice[(left[0][0] + 1) % 24] = left[0][1]
+  refused(twice)
+  far = minus.clone(); far[left[0][0]] = 16
+  refused(far)
+  # the refusals above enqueued nothing: the left utterances can still be taken up, and give the one-call frames
+  want = gm.decode(mem, pm, ln, masks, max_steps)
+  gm.decode(mem, pm, ln, masks, max_steps, leave_unfinished=True)
+  torch.cuda.synchronize()
+  good = minus.clone()
+  rows = [b for b, _ in left]
+  out2 = gm.decode(mem, pm, ln, masks, max_steps, leave_unfinished=True)
+  left2 = [(b, s) for b, (r, s) in enumerate(zip(out2[4].cpu().tolist(), out2[5].cpu().tolist())) if r == 2]
+  assert [b for b, _ in left2] == rows                           # same lines, same launch
+  idx = torch.tensor(rows, device="cuda:0")
+  resume = torch.tensor([s for _, s in left2], dtype=torch.int32, device="cuda:0")
+  fin = gm.decode(mem[idx].contiguous(), pm[idx].contiguous(), ln[idx].contiguous(), masks, max_steps, resume_slots=resume)
+  for j, b in enumerate(rows):
+    n0, n = int(out2[3][b]), int(want[3][b])
+    assert int(fin[3][j]) == n
+    assert torch.equal(fin[0][j][:, n0:n], want[0][b][:, n0:n])
+  stale = torch.tensor([s for _, s in left2], dtype=torch.int32, device="cuda:0")     # ... and not a second time
+  with pytest.raises(TacoError):
+    gm.decode(mem[idx].contiguous(), pm[idx].contiguous(), ln[idx].contiguous(), masks, max_steps, resume_slots=stale)

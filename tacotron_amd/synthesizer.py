@@ -298,7 +298,7 @@ class Synthesizer:
     speakers = None
     if self.hparams.use_speaker_embedding and new_preps:
       speakers = torch.full((len(new_preps), T), new_preps[0].speaker_id, dtype=torch.int64, device=self.device)
-    lens_t = torch.tensor(new_lens, dtype=torch.int32, device=self.device) if new_preps else None
+    lens_t = torch.tensor(new_lens, dtype=torch.int32) if new_preps else None      # (host: the model reads them there too)
     start = time.perf_counter()
     left = None
     if carry or leave_unfinished:

@@ -109,6 +109,34 @@ def test_synthesize_batched_equals_line_by_line(tmp_path):
     np.testing.assert_array_equal(np.load(tmp_path / "one" / n), np.load(tmp_path / "batched" / n))
 
 
+def test_lines_carried_from_launch_to_launch_end_up_in_the_same_files(tmp_path):
+  """The batch mode's carry-over (a launch may leave lines unfinished, they head the next launch and finish there or
+  later) on the host side: with a model that leaves lines at every launch but the last, the command writes the files it
+  writes line by line - every line once, under its own name, with its own frames, --include-stats files included."""
+  from oracle_shim import oracle_synthesizer, oracle_synthesizer_resumable
+  r = np.random.RandomState(3)
+  lines = ["|".join(f"s{r.randint(1, 31)}" for _ in range(r.randint(2, 12))) for _ in range(14)]
+  lines.insert(5, "")
+  text = tmp_path / "in.txt"
+  text.write_text("\n".join(lines), encoding="UTF-8")
+  common = ["synthesize", TINY_CKPT, str(text), "--sep", "|", "--custom-seed", "5", "--max-decoder-steps", "26", "--include-stats"]
+  assert _run(common + ["-out", str(tmp_path / "one")], oracle_synthesizer)
+  made = []
+
+  def factory(*args, **kwargs):
+    made.append(oracle_synthesizer_resumable(*args, **kwargs))
+    return made[-1]
+
+  assert _run(common + ["-out", str(tmp_path / "carried"), "--batch-size", "3"], factory)
+  assert made[0].model.left_total >= 5 and not made[0].model._parked        # lines were left, and all came back
+  names = sorted(p.name for p in (tmp_path / "one").iterdir())
+  assert len([n for n in names if n.endswith(".npy")]) == 3 * 14
+  assert names == sorted(p.name for p in (tmp_path / "carried").iterdir())
+  for n in names:
+    if n.endswith(".npy"):
+      np.testing.assert_array_equal(np.load(tmp_path / "one" / n), np.load(tmp_path / "carried" / n), err_msg=n)
+
+
 def test_synthesize_reproduces_the_reference_record(tmp_path, gate_table):
   """North-Wind line through the command = the reference's Synthesizer.infer output for it."""
   from oracle_shim import oracle_synthesizer

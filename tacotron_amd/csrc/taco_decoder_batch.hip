@@ -314,6 +314,22 @@ constexpr int BT_NAP_UP = 8, BT_NAP_DOWN = 1;
 #ifndef BT_DELAY_DH
 #define BT_DELAY_DH 0
 #endif
+// Diagnostic (timing only, results unchanged): workgroups of role BT_PROBE_ROLE (0 plain, 1 P, 2 M, 3 Q) lose BT_PROBE_N
+// naps of 64 clocks at point BT_PROBE_AT of every frame.  How much of that the frame gets longer by says whether the
+// point lies on the frame's critical path for that role (scripts/probe_delays.sh).
+#ifndef BT_PROBE_AT
+#define BT_PROBE_AT 0
+#endif
+#ifndef BT_PROBE_ROLE
+#define BT_PROBE_ROLE 0
+#endif
+#ifndef BT_PROBE_N
+#define BT_PROBE_N 16
+#endif
+#define BT_PROBE(point)                                                                              \
+  if constexpr (BT_PROBE_AT == (point) && ROLE == BT_PROBE_ROLE) {                                   \
+    for (int i_ = 0; i_ < BT_PROBE_N; ++i_) __builtin_amdgcn_s_sleep(1);                             \
+  }
 __device__ __forceinline__ int bt_nap_adjust(int n, int spun) {
   const bool any = __builtin_amdgcn_readfirstlane(__any(spun) ? 1 : 0) != 0;
   return any ? min(n + BT_NAP_UP, TACO_NAP_MAX) : max(n - BT_NAP_DOWN, 0);
@@ -907,6 +923,7 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
         }
       }
       BT_STAMP(2);
+      BT_PROBE(1)
       f32x4 acc2 = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
       for (int i = 0; i < NL_P; ++i) {
@@ -948,6 +965,7 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
       }
       taco_lds_barrier();
       BT_STAMP(4);
+      BT_PROBE(2)
       {
         // wave w: query values of dimensions 4w .. 4w + 3
         const float* r0 = lds + BT_OPQ(LQ_ROWS + (QR * wave) * KH + lane_f * 4);
@@ -1094,6 +1112,7 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
       }
       taco_lds_barrier();
       BT_STAMP(7);
+      BT_PROBE(3)
       float w_own = 0.0f;
       {
         float e = 0.0f;
@@ -1240,6 +1259,7 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
 #pragma unroll
       for (int i = 6; i < 9; ++i) { BT_MFMA4(wd_c, i, vc[i], acc_d, acc_d2) }
       acc_d += acc_d2;
+      BT_PROBE(4)
       BT_STAMP(20);
       BT_STAMP_W(24, 1); BT_STAMP_W(25, 2); BT_STAMP_W(26, 3);
       const f32x4 pre = bt_reduce_tiles(lds, L_RED, acc_d, wave, lane_f);
@@ -1298,6 +1318,7 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
       // it for products that have until the next context to finish, and let those two groups fetch first)
       if (!(is_p || is_m)) { for (int i = 0; i < BT_DELAY_DH; ++i) __builtin_amdgcn_s_sleep(1); }
       bt_nap_begin(nap_dh, wctx);
+      BT_PROBE(5)
       bt_issue<NL_H>(rs, par + w_lane_dh, vdh);
       BT_SB();
       if (is_p || is_m) {
@@ -1411,6 +1432,7 @@ __global__ __launch_bounds__(TACO_BT_THREADS) void taco_decoder_batch_kernel(con
       }
     }
     // Q: next frame's location term, while the P group works on the next frame's prenet output
+    BT_PROBE(6)
     BT_STAMP(22);
     if (is_q) update_location_term(lane_f);
     BT_STAMP(14);

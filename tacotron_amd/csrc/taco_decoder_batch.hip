@@ -295,7 +295,10 @@ __device__ __forceinline__ float bt_lstm_cell(f32x4 pre, f32x4 bias, float& c) {
 // longer next frame; all there: a little shorter), with a step ratio of 8 : 1 - here a look that comes too early costs a
 // second fetch of a burst, less than a nap that is too long costs every frame (measured on the batch of 64: 4 : 1 -0.4 %,
 // 8 : 1 +1.2 %, 16 : 1 = the batch-1 kernel's ratio 0, 32 : 1 -3.3 %, 64 : 1 -7.7 %; no naps at all -15 %).
-constexpr int BT_NAP_UP = 8, BT_NAP_DOWN = 1;
+#ifndef BT_NAP_UP_STEP
+#define BT_NAP_UP_STEP 8
+#endif
+constexpr int BT_NAP_UP = BT_NAP_UP_STEP, BT_NAP_DOWN = 1;
 // Extra time (units of s_sleep 1, about 64 clocks) that workgroups not on the frame's chain keep away from a vector
 #ifndef BT_DELAY_AH
 #define BT_DELAY_AH 50

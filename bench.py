@@ -363,9 +363,24 @@ def main():
   torch.cuda.set_device(local_rank)
   device = torch.device("cuda", local_rank)
   dist = None
+  barrier_backend = None
   if world > 1:
     import torch.distributed as dist
-    dist.init_process_group("nccl", device_id=device)
+    # The ranks meet only at the timing barriers (no collective on the data path): RCCL, bound to the rank's GPU; if
+    # its set-up fails on this node the same two calls go over gloo on the host instead of losing the measurement
+    # (every rank takes the same branch: the failure of a collective set-up is collective)
+    try:
+      dist.init_process_group("nccl", device_id=device)
+      probe = torch.zeros(1, device=device)
+      dist.all_reduce(probe)
+      torch.cuda.synchronize(device)
+      barrier_backend = "nccl"
+    except Exception as ex:  # pylint: disable=broad-except
+      print(f"bench.py: RCCL set-up failed on rank {rank} ({type(ex).__name__}: {ex}); the timing barriers use gloo", file=sys.stderr, flush=True)
+      if dist.is_initialized():
+        dist.destroy_process_group()
+      dist.init_process_group("gloo")
+      barrier_backend = "gloo"
 
   from tacotron_amd import abi, scenarios
   from tacotron_amd.checkpoint import get_hparams
@@ -390,7 +405,7 @@ def main():
   def max_over_ranks(seconds):
     if dist is None:
       return seconds
-    t = torch.tensor([seconds], device=device, dtype=torch.float64)
+    t = torch.tensor([seconds], device=device if barrier_backend == "nccl" else "cpu", dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -435,6 +450,7 @@ def main():
                                       "ms_per_step": round(elapsed1 / args.steps * 1e3, 4), "steps": args.steps, "warmup": args.warmup,
                                       "note": "measured in this run on every rank's GPU at once (slowest rank), no sharding"}
       out["efficiency"] = round(value / (world * one_gpu), 4)
+      out["barrier_backend"] = barrier_backend
       out["note"] = ("weak scaling of the sharded line set: efficiency = value / (n_gpus x one_gpu_same_workload.value), both measured in "
                      "this run.  `python bench.py --gpus 1` runs the batch-1 headline configuration, a different workload: its value "
                      "must not be used as this curve's one-GPU point (its line carries `lines_one_gpu` for that purpose)")

@@ -2,6 +2,8 @@
 // (encoder and postnet), the encoder BiLSTM recurrence, speaker concat + attention memory projection.
 #include "taco_device.h"
 
+#include <type_traits>
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------
@@ -117,9 +119,11 @@ __global__ __launch_bounds__(256) void taco_conv_kernel(const float* __restrict_
   const int co0 = (by_block ? blockIdx.x : blockIdx.y) * CV_CO;
   const int len = lens ? min(lens[b], T) : T;      // (a length beyond the buffers' T columns is read as T)
   const float* in_b = in + (size_t)b * c_in * T;
-  taco_f32x16 acc, tot;       // the running unit's accumulation chain; the sum of the units before it
+  // acc: a unit's accumulation chain (and, after the slab loop, the tile's sum); acc1: the chain of every other unit in
+  // the loop's steady state; tot: the sum of the units before the running one
+  taco_f32x16 acc, acc1, tot;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = tot[r] = 0.0f;
+  for (int r = 0; r < 16; ++r) acc[r] = acc1[r] = tot[r] = 0.0f;
 
   if (t0 < len) {
     // Staging map.  Weights: thread = (row tid >> 3, segment tid & 7), row = output channel, the thread takes NW
@@ -199,7 +203,13 @@ __global__ __launch_bounds__(256) void taco_conv_kernel(const float* __restrict_
     // runs in the first one's shadow, whatever is bunched up behind the last one does not.  So the slab's staging work
     // - the operand reads of the next step, the global loads, the LDS writes - is dealt out one or two instructions at
     // a time behind each product, and scheduling barriers keep the compiler from gathering it up again.
-    auto slab = [&](int s, float (&fw)[NW], float (&fx)[NXI], const float (&kw)[NW], const float (&kx)[NXI]) {
+    // `cur` is the running unit's chain.  FOLD (a unit's first slab in the steady state): the unit before ran on `prev`; its
+    // sixteen registers join `tot` one at a time behind this slab's first sixteen products - done right at the unit's end
+    // they would stop the product chain for the length of a slab's fortieth (the adds wait for the last product, the next
+    // product for the cleared registers).
+    auto slab = [&](auto fold_c, taco_f32x16& cur, taco_f32x16& prev, int s, float (&fw)[NW], float (&fx)[NXI], const float (&kw)[NW],
+                    const float (&kx)[NXI]) {
+      constexpr bool FOLD = decltype(fold_c)::value;
       const int buf = s & 1;
       const int ci_next = (sl0 + min(s + 2, n_slabs - 1)) * CI;     // past the end: a harmless reload of the last slab
       float av[2][KS], bv[2][KS];
@@ -216,7 +226,10 @@ __global__ __launch_bounds__(256) void taco_conv_kernel(const float* __restrict_
         for (int kk = 0; kk < KS; ++kk) {
           const int m = step * KS + kk;
           if (step + 1 < CI / 4) read_pair(step + 1, (step + 1) & 1, kk);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[step & 1][kk], bv[step & 1][kk], acc, 0, 0, 0);
+          cur = __builtin_amdgcn_mfma_f32_32x32x2f32(av[step & 1][kk], bv[step & 1][kk], cur, 0, 0, 0);
+          if constexpr (FOLD) {
+            if (m < 16) { tot[m] += prev[m]; prev[m] = 0.0f; }
+          }
 #pragma unroll
           for (int it = m * ITEMS / MFMAS; it < (m + 1) * ITEMS / MFMAS; ++it) {
             if (it < LW + LX) load_item(it, ci_next, fw, fx);
@@ -237,17 +250,33 @@ __global__ __launch_bounds__(256) void taco_conv_kernel(const float* __restrict_
     // (Both slabs of a pair unconditionally inside the loop, the odd one behind it: with `if (s + 1 < n_slabs)` around
     // the second, the compiler sees a path from the first slab straight back to the loop's top on which the first
     // slab's loads are still in flight, and drains every load at the top of each pair.)
-    static_assert(TACO_CONV_UNIT_SLABS % 2 == 0, "units are whole pairs of slabs");
+    static_assert(TACO_CONV_UNIT_SLABS == 4 && MFMAS >= 16, "the steady state below spells out two units of four slabs");
+    const std::true_type fold;
+    const std::false_type plain;
     int s = 0;
+    // steady state: two units per round, on alternating chains; a unit's sum joins `tot` during the next unit's first slab
+    // (in unit order: the additions are the ones of the plain loop below)
+    for (; s + 7 < n_slabs; s += 8) {
+      slab(fold, acc, acc1, s, pwA, pxA, pwB, pxB);
+      slab(plain, acc, acc1, s + 1, pwB, pxB, pwA, pxA);
+      slab(plain, acc, acc1, s + 2, pwA, pxA, pwB, pxB);
+      slab(plain, acc, acc1, s + 3, pwB, pxB, pwA, pxA);
+      slab(fold, acc1, acc, s + 4, pwA, pxA, pwB, pxB);
+      slab(plain, acc1, acc, s + 5, pwB, pxB, pwA, pxA);
+      slab(plain, acc1, acc, s + 6, pwA, pxA, pwB, pxB);
+      slab(plain, acc1, acc, s + 7, pwB, pxB, pwA, pxA);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tot[r] += acc1[r];             // the steady state's last unit (zeros if it never ran)
     for (; s + 1 < n_slabs; s += 2) {
-      slab(s, pwA, pxA, pwB, pxB);
-      slab(s + 1, pwB, pxB, pwA, pxA);
+      slab(plain, acc, acc1, s, pwA, pxA, pwB, pxB);
+      slab(plain, acc, acc1, s + 1, pwB, pxB, pwA, pxA);
       if (((s + 2) & (TACO_CONV_UNIT_SLABS - 1)) == 0) {      // a unit is complete: its chain ends here
 #pragma unroll
         for (int r = 0; r < 16; ++r) { tot[r] += acc[r]; acc[r] = 0.0f; }
       }
     }
-    if (s < n_slabs) slab(s, pwA, pxA, pwB, pxB);
+    if (s < n_slabs) slab(plain, acc, acc1, s, pwA, pxA, pwB, pxB);
     // (a last unit of fewer slabs; after a whole number of units this adds zeros)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = tot[r] + acc[r];
